@@ -1,0 +1,225 @@
+"""Properties that pin the oracle beyond the reference's own KATs: the indexed
+matcher equals the verbatim loop, streams inflate with system zlib, the
+chunked build stream degenerates to the reference stream, and the FIFO
+tie-break is one legal outcome of the reference's heap."""
+import os
+import random
+import zlib as sysz
+
+import pytest
+
+from oracle import zref as z
+
+REF = "/root/reference"
+
+
+def _text(rng, n):
+    words = ["the", "of", "and", "compress", "window", "a", "lazy", "match", "huffman", "tree", "zlib", "block",
+             "distance", "literal", "code", "bit", "stream", "to", "in", "is"]
+    out = bytearray()
+    while len(out) < n:
+        out += rng.choice(words).encode() + (b"\n" if rng.random() < 0.1 else b" ")
+    return bytes(out[:n])
+
+
+def _cases():
+    rng = random.Random(1234)
+    cases = [b"", b"a", b"ab", b"abc", b"abcd", b"aaaa", b"aaaaa", b"a" * 300, b"a" * 1200,
+             b"abcabcabcabcabcabcabcabc_abcabc", b"ab" * 700, bytes(range(256)) * 3,
+             b"hello hello hello hello"]
+    for n in (50, 400, 3000):
+        cases.append(_text(rng, n))
+        cases.append(bytes(rng.randrange(256) for _ in range(n)))
+        cases.append(bytes(rng.randrange(2) for _ in range(n)))
+        cases.append(bytes(rng.choice(b"abc") for _ in range(n)))
+    # 16-byte records with zero runs
+    rec = bytearray()
+    for i in range(120):
+        rec += i.to_bytes(4, "little") + bytes([rng.randrange(16), 0, 0, 0]) + bytes([rng.randrange(256) for _ in range(3)]) + b"\x3f" + bytes(4)
+    cases.append(bytes(rec))
+    return cases
+
+
+def test_survey_derived_vectors():
+    """Values derived in the survey session from a scratch transcription (not a
+    Rust run): they must agree with this independent restatement."""
+    assert z.compress_reference(b"", z.FIXED).hex() == "7801030000000001"
+    assert z.compress_reference(b"a", z.FIXED).hex() == "78014b040000620062"
+    assert z.compress_reference(b"abcd", z.FIXED).hex() == "78014b4c4a4e010003d8018b"
+    assert z.compress_reference(b"a", z.DYNAMIC).hex() == "78010dc181080000000020d6fd25ae0400620062"
+    toks = z.lz77_zlib(b"a" * 1200)
+    assert [z.tok_str(t) for t in toks[259:]] == ["M(257,259)", "M(257,516)", "M(257,773)", "M(170,1030)"]
+    assert toks[:259] == [97] * 259
+    toks = z.lz77_zlib(b"abcabcabcabcabcabcabcabc_abcabc")
+    assert [z.tok_str(t) for t in toks[14:]] == ["M(10,12)", "L(95)", "M(6,25)"]
+    with pytest.raises(z.OracleError) as e:  # single distance symbol: the reference panics
+        z.compress_reference(b"hello hello hello hello", z.DYNAMIC)
+    assert e.value.code == z.PANIC_ZERO_LEN_CODE
+    with pytest.raises(z.OracleError):  # empty input with Dynamic panics too
+        z.compress_reference(b"", z.DYNAMIC)
+
+
+def test_fast_matcher_equals_verbatim_loop():
+    for data in _cases():
+        assert z.lz77_zlib(data, fast=True) == z.lz77_zlib(data, fast=False), data[:40]
+        if len(data) > 10:
+            for start in (1, len(data) // 2, len(data) - 2):
+                assert z.lz77_zlib(data, start, fast=True) == z.lz77_zlib(data, start, fast=False)
+    rng = random.Random(7)
+    for _ in range(60):
+        n = rng.randrange(0, 600)
+        alpha = rng.choice([b"ab", b"abc", b"abcdefgh", bytes(range(256))])
+        data = bytes(rng.choice(alpha) for _ in range(n))
+        start = rng.randrange(0, n + 1)
+        for window, max_len in ((32768, 258), (64, 258), (200, 20), (5, 6)):
+            a = z.lz77_fast(data, start, window, max_len)
+            b = z.lz77_compress(data, start, window, 3, max_len)
+            assert a == b
+            assert z.detokenize(a, data[:start]) == data[start:]
+
+
+def test_literal_compare_mode_is_identical():
+    rng = random.Random(3)
+    for data in (_text(rng, 2000), b"a" * 700, bytes(rng.randrange(3) for _ in range(900))):
+        assert z.lz77_compress(data, 0, 32768, 3, 258, literal_compare=True) == z.lz77_zlib(data)
+
+
+def test_token_invariants():
+    """Consequences of the reference loop: no overlapping match, distance >=
+    length + 2, length <= 257, no match starts in the last three bytes."""
+    rng = random.Random(5)
+    for data in _cases() + [_text(rng, 20000)]:
+        toks = z.lz77_zlib(data, fast=True)
+        assert z.detokenize(toks) == data
+        pos = 0
+        for t in toks:
+            if t & z.TOK_MARKER:
+                ln, d = (t >> 16) & 0x1FF, t & 0xFFFF
+                assert 3 <= ln <= 257 and d >= ln + 2 and d <= 32768
+                assert pos < len(data) - 3
+                pos += ln
+            else:
+                pos += 1
+
+
+@pytest.mark.parametrize("strategy", [z.FIXED, z.DYNAMIC, z.RAW, z.AUTO])
+def test_chunked_streams_inflate_everywhere(strategy):
+    for data in _cases():
+        for chunk in (1 << 20, 1024, 97):
+            s = z.compress_chunked(data, strategy, chunk, fast=True)
+            assert s[:2] == b"\x78\x01"
+            assert sysz.decompress(s) == data
+            assert z.decompress(s) == data
+            assert s[-4:] == sysz.adler32(data).to_bytes(4, "big")
+
+
+def test_chunked_equals_reference_when_one_chunk():
+    n_equal = 0
+    for data in _cases():
+        for strategy in (z.FIXED, z.DYNAMIC, z.RAW, z.AUTO):
+            try:
+                ref = z.compress_reference(data, strategy)
+            except z.OracleError as e:
+                assert e.code <= -100
+                continue
+            assert z.compress_chunked(data, strategy, 1 << 20, fast=False) == ref
+            n_equal += 1
+    assert n_equal > 40
+
+
+def test_adler_matches_system_zlib():
+    rng = random.Random(11)
+    for n in (0, 1, 2, 5551, 5552, 5553, 70000):
+        data = bytes(rng.randrange(256) for _ in range(n))
+        assert z.adler32(data) == sysz.adler32(data)
+    assert z.adler32(b"\xff" * 100000) == sysz.adler32(b"\xff" * 100000)
+
+
+def test_fifo_tie_break_is_a_legal_heap_outcome():
+    """Total coded bits are the same for every heap order; exact lengths agree
+    whenever the heap simulation itself is order independent."""
+    rng = random.Random(21)
+    for trial in range(40):
+        nsym = rng.randrange(2, 60)
+        freq = {s: rng.choice([1, 1, 2, 3, 5, 8, rng.randrange(1, 500)]) for s in rng.sample(range(286), nsym)}
+        fifo = z.Tree.from_freq(freq)
+        fifo.assign()
+        cost = lambda t: sum(freq[s] * l for s, (_, l) in t.encodings().items())
+        outcomes = set()
+        for seed in range(6):
+            h = z.Tree.from_freq(freq, z.TIE_HEAP, seed)
+            h.assign()
+            assert cost(h) == cost(fifo)
+            assert sum(2.0 ** -l for _, l in h.encodings().values()) == 1.0
+            outcomes.add(tuple(sorted((s, l) for s, (_, l) in h.encodings().items())))
+        if len(outcomes) == 1:
+            pass  # order independent here; FIFO may still differ only through internal ties
+        assert sum(2.0 ** -l for _, l in fifo.encodings().values()) == 1.0
+    # distinct weights with no equal internal sums: every order gives the same lengths
+    freq = {i: 3 ** i for i in range(8)}
+    a = z.Tree.from_freq(freq)
+    a.assign()
+    for seed in range(5):
+        b = z.Tree.from_freq(freq, z.TIE_HEAP, seed)
+        b.assign()
+        assert {s: l for s, (_, l) in a.encodings().items()} == {s: l for s, (_, l) in b.encodings().items()}
+
+
+def test_build_length_limit_and_lone_symbol():
+    # Fibonacci weights force depth > 15
+    fib = [1, 1]
+    while len(fib) < 30:
+        fib.append(fib[-1] + fib[-2])
+    toks = []
+    for s, c in enumerate(fib):
+        toks += [s] * c
+    ll_len, ll_code, d_len, d_code = z.chunk_tables(toks)
+    used = [l for l in ll_len if l]
+    assert max(used) == 15 and abs(sum(2.0 ** -l for l in used) - 1.0) < 1e-12
+    assert all(l == 0 for l in d_len)
+    # lone distance symbol gets one bit
+    toks = [ord("a")] * 10 + [z.marker(3, 7)]
+    _, _, d_len, d_code = z.chunk_tables(toks)
+    assert d_len[z.get_distance_code(7)] == 1 and sum(1 for l in d_len if l) == 1
+    s = z.compress_chunked(b"hello hello hello hello", z.DYNAMIC)
+    assert sysz.decompress(s) == b"hello hello hello hello"
+    assert sysz.decompress(z.compress_chunked(b"", z.DYNAMIC)) == b""
+    big = bytes(toks_ & 0xFF for toks_ in range(256)) * 2
+    assert sysz.decompress(z.compress_chunked(big, z.DYNAMIC)) == big
+
+
+def test_auto_choice_thresholds():
+    assert z.auto_choice(b"x" * 255) == z.RAW
+    assert z.auto_choice(b"x" * 256) == z.FIXED
+    assert z.auto_choice(b"x" * 1023) == z.FIXED
+    rng = random.Random(2)
+    assert z.auto_choice(bytes(rng.randrange(256) for _ in range(4096))) in (z.FIXED, z.DYNAMIC)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+@pytest.mark.parametrize("strategy", [z.FIXED, z.DYNAMIC, z.AUTO])
+def test_reference_integration_files(strategy):
+    """tests/test_zlib.rs:30-115: round trip on LICENSE and every file under src/."""
+    files = [os.path.join(REF, "LICENSE")] + sorted(
+        os.path.join(REF, "src", f) for f in os.listdir(os.path.join(REF, "src")))
+    for path in files:
+        data = open(path, "rb").read()
+        s = z.compress_reference(data, strategy)
+        assert z.decompress(s) == data
+        assert sysz.decompress(s) == data
+        assert z.compress_chunked(data, strategy, 1 << 20, fast=True) == s
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+def test_reference_file_sizes_match_survey():
+    """Stream sizes (Dynamic / Fixed) recorded in the survey for the reference's
+    own test inputs; a few bytes of slack on Dynamic for the heap tie-break."""
+    expect = {"huffman.rs": (8420, 9607), "compress.rs": (7435, 8455), "decompress.rs": (3844, 4424),
+              "lz77.rs": (2383, 2679), "bitwriter.rs": (1434, 1639), "bitreader.rs": (1335, 1541),
+              "adler.rs": (236, 254), "lib.rs": (92, 87)}
+    for name, (dyn, fix) in expect.items():
+        data = open(os.path.join(REF, "src", name), "rb").read()
+        assert len(z.compress_reference(data, z.FIXED)) == fix
+        assert abs(len(z.compress_reference(data, z.DYNAMIC)) - dyn) <= 4
+    lic = open(os.path.join(REF, "LICENSE"), "rb").read()
+    assert len(z.compress_reference(lic, z.FIXED)) == 819
