@@ -1,0 +1,144 @@
+/*
+ * zlib_amd.h -- C ABI of the MI355X-native DEFLATE/zlib compressor.
+ *
+ * This is the boundary a binding of the mkpro118/zlib crate would call
+ * (Rust `extern "C"` block, Python ctypes, ...).  Plain pointers and sizes
+ * only.  Every compute entry point runs hand-written HIP kernels for gfx950;
+ * there is no CPU fallback: without a usable GPU the calls return
+ * ZG_ERR_NO_DEVICE.
+ *
+ * Conventions: 0 = success, negative = error (zg_strerror); the library
+ * allocates host outputs with malloc and the caller releases them with
+ * zg_free; nothing unwinds or aborts across the boundary.  A zg_ctx owns one
+ * HIP stream and its scratch buffers on one device; calls on the same ctx are
+ * serialised by an internal mutex, different ctx objects are independent.
+ * Passing ctx == NULL uses a lazily created process-wide context on the
+ * current HIP device.
+ *
+ * Reference items each entry point stands in for are cited as file:line of
+ * the reference crate.
+ */
+#ifndef ZLIB_AMD_H
+#define ZLIB_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ---- */
+enum {
+    ZG_OK = 0,
+    ZG_ERR_ARG = -1,         /* bad argument                                         */
+    ZG_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at init           */
+    ZG_ERR_HIP = -3,         /* a HIP call failed (zg_last_error has the text)        */
+    ZG_ERR_NOMEM = -4,       /* host or device allocation failed                      */
+    ZG_ERR_CAPACITY = -5,    /* caller-provided output buffer too small               */
+    ZG_ERR_UNSUPPORTED = -6, /* parameters outside what the device path implements    */
+    ZG_ERR_INTERNAL = -7     /* a device-side consistency check failed                */
+};
+
+/* Strategy: src/compress.rs:28-34 (same order). */
+enum { ZG_AUTO = 0, ZG_DYNAMIC = 1, ZG_FIXED = 2, ZG_RAW = 3 };
+
+/* Packed LZ77 unit (src/lz77.rs:23-27): Literal(b) = b (0..255);
+ * Marker(len, dist) = 0x80000000 | len << 16 | dist. */
+#define ZG_TOK_MARKER 0x80000000u
+#define ZG_TOK_IS_MARKER(t) (((t) & ZG_TOK_MARKER) != 0)
+#define ZG_TOK_LEN(t) (((t) >> 16) & 0x1FFu)
+#define ZG_TOK_DIST(t) ((t) & 0xFFFFu)
+
+typedef struct zg_ctx zg_ctx;
+
+/* Options; zero-initialise for defaults. */
+typedef struct zg_opts {
+    size_t chunk_bytes; /* input bytes per DEFLATE block; 0 = 1 MiB; multiple of 1024 */
+    size_t batch_bytes; /* input bytes processed per pass over the scratch buffers; 0 = 256 MiB */
+} zg_opts;
+
+/* ---- context ---- */
+int zg_init(int device, zg_ctx **ctx);
+void zg_destroy(zg_ctx *ctx);
+const char *zg_strerror(int code);
+const char *zg_last_error(zg_ctx *ctx); /* text of the last HIP failure on this ctx */
+void zg_free(void *p);
+
+/* ---- zlib::compress(&[u8], &Strategy) -> Vec<u8>   (src/compress.rs:51-86) ----
+ * Host buffers in and out.  The stream is 78 01, one DEFLATE block per chunk
+ * (each matched against the preceding 32 KiB of input), BFINAL on the last,
+ * Adler-32 big-endian.  With n <= chunk_bytes it is the reference's stream
+ * byte for byte wherever the reference does not panic. */
+int zg_compress(zg_ctx *ctx, const uint8_t *in, size_t n, int strategy, const zg_opts *opts,
+                uint8_t **out, size_t *out_n);
+
+/* Same with device-resident input and output (d_in, d_out are device pointers
+ * on the ctx's device; d_out needs zg_compress_bound bytes, 4-byte aligned).
+ * Runs on the ctx stream and synchronises it before returning *out_n. */
+size_t zg_compress_bound(size_t n, int strategy, const zg_opts *opts);
+int zg_compress_device(zg_ctx *ctx, const void *d_in, size_t n, int strategy, const zg_opts *opts,
+                       void *d_out, size_t out_cap, size_t *out_n);
+
+/* ---- sharded compress: one rank of a multi-GPU job ----
+ * A rank owns `n` input bytes (a whole number of chunks unless it is the last
+ * rank) and sees `halo` (<= 32768) bytes of the input that precede them:
+ * d_in points at the first halo byte.  zg_shard_begin runs everything up to
+ * the block bit lengths and reports the rank's totals; after the ranks have
+ * exchanged them, zg_shard_finish packs the rank's blocks at bit phase
+ * (base_bit % 8) into d_out.  Byte 0 of d_out is byte base_bit/8 of the final
+ * stream; when the phase is non-zero it holds only this rank's bits and must
+ * be OR-ed with the previous rank's last byte.  first_rank writes the 78 01
+ * header (base_bit must then be 0), last_rank sets BFINAL on its last block
+ * and appends the Adler-32 passed in `adler` (combined by the caller with
+ * zg_adler32_combine). */
+typedef struct zg_shard_info {
+    uint64_t total_bits; /* bits of all blocks of this rank (no zlib header/trailer) */
+    uint32_t adler;      /* Adler-32 of this rank's n bytes taken alone             */
+    uint32_t n_chunks;
+} zg_shard_info;
+int zg_shard_begin(zg_ctx *ctx, const void *d_in, size_t halo, size_t n, int strategy,
+                   const zg_opts *opts, int last_rank, zg_shard_info *info);
+int zg_shard_finish(zg_ctx *ctx, uint64_t base_bit, int first_rank, int last_rank, uint32_t adler,
+                    void *d_out, size_t out_cap, size_t *out_bytes);
+uint32_t zg_adler32_combine(uint32_t adler1, uint32_t adler2, uint64_t len2);
+
+/* ---- zlib::adler::adler32(&[u8]) -> u32   (src/adler.rs:5-13) ---- */
+int zg_adler32(zg_ctx *ctx, const uint8_t *in, size_t n, uint32_t *out);
+int zg_adler32_device(zg_ctx *ctx, const void *d_in, size_t n, uint32_t *out);
+
+/* ---- LZ77Compressor::compress(&self, &[u8]) -> Vec<LZ77Unit>   (src/lz77.rs:143-207) ----
+ * window/min_len/max_len are the public fields of LZ77Compressor
+ * (src/lz77.rs:31-38; defaults 144/5/100, zlib 32768/3/258).  Positions
+ * before `start` are window only (start = 0 is the reference call).  The
+ * device path needs 3 <= min_len and max_len <= 258 (ZG_ERR_UNSUPPORTED
+ * otherwise). */
+int zg_lz77(zg_ctx *ctx, const uint8_t *in, size_t n, size_t start, uint32_t window, uint32_t min_len,
+            uint32_t max_len, uint32_t **tokens, size_t *n_tokens);
+
+/* ---- HuffmanTree::from_lz77 + assign + to_canonical   (src/huffman.rs:238-288,
+ * 619-645, 714-734; src/compress.rs:296-314) ----
+ * Code lengths and LSB-first (bit-reversed) codes of the two canonical trees
+ * for a token stream; unused symbols have length 0. */
+int zg_huffman_from_tokens(zg_ctx *ctx, const uint32_t *tokens, size_t n, uint8_t ll_len[286],
+                           uint16_t ll_code[286], uint8_t d_len[30], uint16_t d_code[30]);
+
+/* ---- measurement ----
+ * With profiling on, every kernel launch is bracketed by HIP events on the
+ * ctx stream; zg_profile_get returns accumulated milliseconds and launch
+ * counts per kernel since the last zg_profile_reset. */
+int zg_profile_enable(zg_ctx *ctx, int on);
+int zg_profile_reset(zg_ctx *ctx);
+int zg_profile_count(zg_ctx *ctx);
+int zg_profile_get(zg_ctx *ctx, int index, const char **name, double *ms, uint64_t *launches);
+
+/* ---- synthetic corpora for tests and benchmarks (host side) ----
+ * kind: 0 text, 1 random, 2 structured binary, 3 mixed (text/random/text/binary
+ * per MiB), 4 records.  Deterministic in (kind, seed, offset): buf receives
+ * bytes [offset, offset+n) of the corpus. */
+int zg_corpus_fill(int kind, uint64_t seed, uint64_t offset, uint8_t *buf, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

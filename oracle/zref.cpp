@@ -1434,6 +1434,17 @@ int zo_block_bits(const uint32_t *tokens, size_t n, int strategy, uint64_t *bits
     return rc;
 }
 
+int zo_write_block(const uint32_t *tokens, size_t n, int strategy, int bfinal, uint8_t **out, size_t *out_n,
+                   uint64_t *bits) {
+    zo_bw w;
+    int rc = write_block(&w, tokens, n, strategy, bfinal != 0, false);
+    *bits = w.bitpos();
+    bw_flush_byte(&w);
+    *out = dup_out(w.buffer);
+    *out_n = w.buffer.size();
+    return rc;
+}
+
 int zo_auto_choice(const uint8_t *data, size_t n) { return auto_choice(data, n); }
 }
 

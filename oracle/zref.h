@@ -175,6 +175,9 @@ int zo_chunk_tables(const uint32_t *tokens, size_t n, uint8_t ll_len[286], uint1
 /* Bit length of the block the build emits for these tokens (3 header bits +
  * dynamic header + payload + EOB); strategy ZO_DYNAMIC or ZO_FIXED. */
 int zo_block_bits(const uint32_t *tokens, size_t n, int strategy, uint64_t *bits);
+/* The bytes of that block alone (zero padded to a byte) and its bit length. */
+int zo_write_block(const uint32_t *tokens, size_t n, int strategy, int bfinal, uint8_t **out, size_t *out_n,
+                   uint64_t *bits);
 /* Strategy::Auto decision (src/compress.rs:89-169): returns ZO_RAW/FIXED/DYNAMIC. */
 int zo_auto_choice(const uint8_t *data, size_t n);
 

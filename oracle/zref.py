@@ -114,6 +114,7 @@ def _declare(L):
     f("zo_chunk_tokens", C.c_int, C.c_char_p, _sz, _sz, _sz, C.c_int, C.POINTER(_u32p), _szp)
     f("zo_chunk_tables", C.c_int, _u32p, _sz, _u8p, C.POINTER(C.c_uint16), _u8p, C.POINTER(C.c_uint16))
     f("zo_block_bits", C.c_int, _u32p, _sz, C.c_int, C.POINTER(C.c_uint64))
+    f("zo_write_block", C.c_int, _u32p, _sz, C.c_int, C.c_int, C.POINTER(_u8p), _szp, C.POINTER(C.c_uint64))
     f("zo_auto_choice", C.c_int, C.c_char_p, _sz)
     f("zo_decompress", C.c_int, C.c_char_p, _sz, C.POINTER(_u8p), _szp, C.c_char_p, _sz)
     f("zo_bench_slices", C.c_int, C.c_char_p, _szp, _szp, _szp, _sz, C.c_int, C.POINTER(C.c_uint64))
@@ -487,6 +488,13 @@ def block_bits(tokens, strategy=DYNAMIC) -> int:
     b = C.c_uint64()
     _check(lib().zo_block_bits(_tok_array(tokens), len(tokens), strategy, C.byref(b)))
     return b.value
+
+
+def write_block(tokens, strategy=DYNAMIC, bfinal=True):
+    """(bytes, bit length) of the single block the build emits for `tokens`."""
+    p, n, b = _u8p(), C.c_size_t(), C.c_uint64()
+    _check(lib().zo_write_block(_tok_array(tokens), len(tokens), strategy, int(bfinal), C.byref(p), C.byref(n), C.byref(b)))
+    return _take_bytes(p, n), b.value
 
 
 def auto_choice(data: bytes) -> int:

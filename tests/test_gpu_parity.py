@@ -1,0 +1,126 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle."""
+import random
+import zlib as sysz
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def za():
+    import zlib_amd
+    zlib_amd.default_context()
+    return zlib_amd
+
+
+@pytest.fixture(scope="module")
+def z():
+    from oracle import zref
+    zref.lib()
+    return zref
+
+
+def _small_cases():
+    rng = random.Random(1234)
+    cases = [b"", b"a", b"ab", b"abc", b"abcd", b"aaaa", b"aaaaa", b"a" * 300, b"a" * 1200,
+             b"abcabcabcabcabcabcabcabc_abcabc", b"ab" * 700, bytes(range(256)) * 3, b"hello hello hello hello"]
+    for n in (50, 400, 3000):
+        cases.append(bytes(rng.randrange(256) for _ in range(n)))
+        cases.append(bytes(rng.randrange(2) for _ in range(n)))
+        cases.append(bytes(rng.choice(b"abc") for _ in range(n)))
+    return cases
+
+
+def test_adler32(za, z):
+    rng = random.Random(3)
+    for n in (0, 1, 15, 16, 17, 5552, 70000, 300000, 1 << 20):
+        data = bytes(rng.randrange(256) for _ in range(min(n, 4096))) * (n // 4096 + 1)
+        data = data[:n]
+        assert za.adler32(data) == z.adler32(data) == sysz.adler32(data)
+    assert za.adler32(b"\xff" * 3_000_000) == sysz.adler32(b"\xff" * 3_000_000)
+
+
+def test_lz77_tokens_small(za, z):
+    comp = za.zlib_compressor()
+    for data in _small_cases():
+        assert comp.compress_packed(data) == z.lz77_zlib(data, fast=True), data[:32]
+        if len(data) > 10:
+            for start in (1, len(data) // 2, len(data) - 2):
+                assert comp.compress_packed(data, start=start) == z.lz77_zlib(data, start, fast=True)
+
+
+def test_lz77_default_parameters(za, z):
+    """LZ77Compressor::new() uses window 144, min 5, max 100 (src/lz77.rs:18-21)."""
+    comp = za.LZ77Compressor.new()
+    rng = random.Random(8)
+    cases = [b"ABCBDBDBDBDBDBDBCBADBSB", b"hi hi hello hi hi wow hello hi", b"abcdefabcdefabcdef",
+             b"abcdefghijklmnopqrstuvwxyz" * 100, b"a" * 1000, bytes(range(255))]
+    cases += [bytes(rng.choice(b"abcd") for _ in range(2000))]
+    for data in cases:
+        assert comp.compress_packed(data) == z.lz77_compress(data), data[:32]
+    small, large = za.LZ77Compressor.with_window_size(64), za.LZ77Compressor.with_window_size(1024)
+    inp = b"abcdefghijklmnopqrstuvwxyz" * 100
+    assert small.compress_packed(inp) == z.lz77_compress(inp, window=64)
+    assert large.compress_packed(inp) == z.lz77_compress(inp, window=1024)
+    assert len(small.compress(inp)) > len(large.compress(inp))  # lz77.rs:317-327
+
+
+def test_lz77_tokens_text_and_binary(za, z):
+    comp = za.zlib_compressor()
+    for kind, n in (("text", 200_000), ("binary", 100_000), ("random", 70_000), ("mixed", 150_000)):
+        data = za.corpus(kind, n)
+        assert comp.compress_packed(data) == z.lz77_zlib(data, fast=True), kind
+
+
+def test_huffman_tables(za, z):
+    rng = random.Random(4)
+    for data in [za.corpus("text", 50_000), za.corpus("binary", 30_000), b"a" * 5000, b"hello hello hello hello", b""]:
+        toks = z.lz77_zlib(data, fast=True)
+        lt, dt = za.HuffmanTree.from_lz77(toks, za.zlib_compressor())
+        ll_len, ll_code, d_len, d_code = z.chunk_tables(toks)
+        assert lt.encodings() == {s: (ll_code[s], ll_len[s]) for s in range(286) if ll_len[s]}
+        assert dt.encodings() == {s: (d_code[s], d_len[s]) for s in range(30) if d_len[s]}
+
+
+@pytest.mark.parametrize("strategy", ["Dynamic", "Fixed", "Raw", "Auto"])
+def test_streams_small(za, z, strategy):
+    st, zs = getattr(za.Strategy, strategy), getattr(z, strategy.upper())
+    for data in _small_cases():
+        for chunk in (1 << 20, 1024):
+            got = za.compress(data, st, chunk_bytes=chunk)
+            assert got == z.compress_chunked(data, zs, chunk, fast=True), (data[:32], chunk)
+            assert sysz.decompress(got) == data
+
+
+@pytest.mark.parametrize("strategy", ["Dynamic", "Fixed"])
+def test_streams_equal_reference_single_chunk(za, z, strategy):
+    """n <= chunk_bytes: the stream is the reference crate's stream byte for byte."""
+    st, zs = getattr(za.Strategy, strategy), getattr(z, strategy.upper())
+    for data in [za.corpus("text", 30_000), za.corpus("text", 3000, seed=7), b"a" * 1200, b"abcd"]:
+        assert za.compress(data, st) == z.compress_reference(data, zs)
+
+
+@pytest.mark.parametrize("kind,n,chunk", [("text", 300_000, 65536), ("mixed", 3 << 20, 1 << 20),
+                                          ("binary", 200_000, 32768), ("random", 100_000, 16384),
+                                          ("text", 1_000_000, 1 << 20), ("records", 40_960, 4096)])
+def test_streams_corpora(za, z, kind, n, chunk):
+    data = za.corpus(kind, n)
+    got = za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk)
+    assert sysz.decompress(got) == data
+    assert got == z.compress_chunked(data, z.DYNAMIC, chunk, fast=True)
+    assert z.decompress(got) == data
+
+
+def test_batching_does_not_change_the_stream(za):
+    data = za.corpus("text", 700_000)
+    a = za.compress(data, za.Strategy.Dynamic, chunk_bytes=65536)
+    b = za.compress(data, za.Strategy.Dynamic, chunk_bytes=65536, batch_bytes=131072)
+    assert a == b
+
+
+def test_raw_large(za, z):
+    data = za.corpus("random", 1_000_003)
+    got = za.compress(data, za.Strategy.Raw)
+    assert got == z.compress_chunked(data, z.RAW, 1 << 20)
+    assert sysz.decompress(got) == data

@@ -1,0 +1,296 @@
+"""Host-side mirror of the reference crate's public items for the compress
+path, on top of the C ABI (same names, argument meaning and error behaviour):
+
+    zlib::compress(&data, &Strategy) -> Vec<u8>        src/compress.rs:51
+    zlib::compress::Strategy                            src/compress.rs:28-34
+    zlib::adler::adler32                                src/adler.rs:5
+    zlib::lz77::{LZ77Unit, LZ77Compressor}              src/lz77.rs:23-38
+    zlib::huffman::HuffmanTree::from_lz77 (+ assign, to_canonical, encode)
+                                                        src/huffman.rs:238, 619, 668, 714
+
+Failures of `compress` surface as exceptions (the crate panics); nothing here
+computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple, Union
+
+from . import _lib
+from ._lib import Opts, ShardInfo, ZgError
+
+ZLIB_WINDOW_SIZE = 1 << 15       # src/huffman.rs:47
+ZLIB_MIN_STRING_LENGTH = 3       # src/huffman.rs:48
+ZLIB_MAX_STRING_LENGTH = 258     # src/huffman.rs:49
+MAX_WINDOW_SIZE = 1 << 15        # src/lz77.rs:20
+
+TOK_MARKER = 0x80000000
+
+
+class Strategy(enum.IntEnum):
+    """src/compress.rs:28-34"""
+    Auto = 0
+    Dynamic = 1
+    Fixed = 2
+    Raw = 3
+
+
+class Context:
+    """One HIP stream plus scratch buffers on one device (zg_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        rc = _lib.lib().zg_init(device, C.byref(self._h))
+        if rc:
+            raise ZgError(rc)
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            _lib.lib().zg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- measurement -------------------------------------------------------
+    def profile(self, on: bool = True):
+        _check(_lib.lib().zg_profile_enable(self._h, int(on)), self)
+
+    def profile_reset(self):
+        _check(_lib.lib().zg_profile_reset(self._h), self)
+
+    def profile_get(self):
+        """{kernel name: (milliseconds, launches)} accumulated since the last reset."""
+        L = _lib.lib()
+        out = {}
+        for i in range(L.zg_profile_count(self._h)):
+            name, ms, n = C.c_char_p(), C.c_double(), C.c_uint64()
+            _check(L.zg_profile_get(self._h, i, C.byref(name), C.byref(ms), C.byref(n)), self)
+            out[name.value.decode()] = (ms.value, n.value)
+        return out
+
+
+_default: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default
+    if _default is None:
+        _default = Context(0)
+    return _default
+
+
+def _check(rc: int, ctx: Optional[Context] = None):
+    if rc:
+        detail = ""
+        if rc == _lib.ERR_HIP and ctx is not None:
+            detail = _lib.lib().zg_last_error(ctx.handle).decode()
+        raise ZgError(rc, detail)
+
+
+def _opts(chunk_bytes: int = 0, batch_bytes: int = 0):
+    return Opts(chunk_bytes, batch_bytes)
+
+
+def compress(data: bytes, strategy: Strategy = Strategy.Auto, *, chunk_bytes: int = 0, batch_bytes: int = 0,
+             ctx: Optional[Context] = None) -> bytes:
+    """zlib::compress(&data, &strategy)."""
+    ctx = ctx or default_context()
+    data = bytes(data)
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    o = _opts(chunk_bytes, batch_bytes)
+    _check(_lib.lib().zg_compress(ctx.handle, data, len(data), int(strategy), C.byref(o), C.byref(out), C.byref(n)), ctx)
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        _lib.lib().zg_free(out)
+
+
+def compress_bound(n: int, strategy: Strategy = Strategy.Dynamic, *, chunk_bytes: int = 0) -> int:
+    o = _opts(chunk_bytes)
+    return _lib.lib().zg_compress_bound(n, int(strategy), C.byref(o))
+
+
+def compress_device(d_in: int, n: int, d_out: int, out_cap: int, strategy: Strategy = Strategy.Dynamic, *,
+                    chunk_bytes: int = 0, batch_bytes: int = 0, ctx: Optional[Context] = None) -> int:
+    """Device pointers in and out (e.g. torch tensors' data_ptr()); returns the stream length."""
+    ctx = ctx or default_context()
+    n_out = C.c_size_t()
+    o = _opts(chunk_bytes, batch_bytes)
+    _check(_lib.lib().zg_compress_device(ctx.handle, d_in, n, int(strategy), C.byref(o), d_out, out_cap, C.byref(n_out)), ctx)
+    return n_out.value
+
+
+def shard_begin(d_in: int, halo: int, n: int, strategy: Strategy, last_rank: bool, *, chunk_bytes: int = 0,
+                ctx: Optional[Context] = None) -> ShardInfo:
+    ctx = ctx or default_context()
+    info = ShardInfo()
+    o = _opts(chunk_bytes)
+    _check(_lib.lib().zg_shard_begin(ctx.handle, d_in, halo, n, int(strategy), C.byref(o), int(last_rank), C.byref(info)), ctx)
+    return info
+
+
+def shard_finish(base_bit: int, first_rank: bool, last_rank: bool, adler: int, d_out: int, out_cap: int, *,
+                 ctx: Optional[Context] = None) -> int:
+    ctx = ctx or default_context()
+    n_out = C.c_size_t()
+    _check(_lib.lib().zg_shard_finish(ctx.handle, base_bit, int(first_rank), int(last_rank), adler, d_out, out_cap,
+                                      C.byref(n_out)), ctx)
+    return n_out.value
+
+
+def adler32_combine(adler1: int, adler2: int, len2: int) -> int:
+    return _lib.lib().zg_adler32_combine(adler1, adler2, len2)
+
+
+def adler32(data: bytes, *, ctx: Optional[Context] = None) -> int:
+    """zlib::adler::adler32(&data)."""
+    ctx = ctx or default_context()
+    data = bytes(data)
+    out = C.c_uint32()
+    _check(_lib.lib().zg_adler32(ctx.handle, data, len(data), C.byref(out)), ctx)
+    return out.value
+
+
+@dataclass(frozen=True, order=True)
+class Literal:
+    """LZ77Unit::Literal(u8)"""
+    byte: int
+
+
+@dataclass(frozen=True, order=True)
+class Marker:
+    """LZ77Unit::Marker(length, distance)"""
+    length: int
+    distance: int
+
+
+LZ77Unit = Union[Literal, Marker]
+
+
+def unpack_units(tokens: Sequence[int]) -> List[LZ77Unit]:
+    return [Marker((t >> 16) & 0x1FF, t & 0xFFFF) if t & TOK_MARKER else Literal(t & 0xFF) for t in tokens]
+
+
+def pack_units(units: Sequence[LZ77Unit]) -> List[int]:
+    return [TOK_MARKER | (u.length << 16) | u.distance if isinstance(u, Marker) else u.byte for u in units]
+
+
+class LZ77Compressor:
+    """src/lz77.rs:31-207: public fields window_size / min_match_length /
+    max_match_length with the crate's defaults (144 / 5 / 100)."""
+
+    def __init__(self):
+        self.window_size = 144
+        self.min_match_length = 5
+        self.max_match_length = 100
+
+    @classmethod
+    def new(cls):
+        return cls()
+
+    @classmethod
+    def with_window_size(cls, window_size: int):
+        c = cls()
+        c.window_size = min(window_size, MAX_WINDOW_SIZE)
+        return c
+
+    def set_window_size(self, newsize: int):
+        self.window_size = min(newsize, MAX_WINDOW_SIZE)
+        return self
+
+    def compress_packed(self, data: bytes, *, start: int = 0, ctx: Optional[Context] = None) -> List[int]:
+        ctx = ctx or default_context()
+        data = bytes(data)
+        toks, n = C.POINTER(C.c_uint32)(), C.c_size_t()
+        _check(_lib.lib().zg_lz77(ctx.handle, data, len(data), start, self.window_size, self.min_match_length,
+                                  self.max_match_length, C.byref(toks), C.byref(n)), ctx)
+        try:
+            return [toks[i] for i in range(n.value)]
+        finally:
+            _lib.lib().zg_free(toks)
+
+    def compress(self, data: bytes, *, ctx: Optional[Context] = None) -> List[LZ77Unit]:
+        """LZ77Compressor::compress(&self, &data) -> Vec<LZ77Unit>"""
+        return unpack_units(self.compress_packed(data, ctx=ctx))
+
+
+def zlib_compressor() -> LZ77Compressor:
+    """get_zlib_compressor, src/compress.rs:451-456"""
+    c = LZ77Compressor.with_window_size(ZLIB_WINDOW_SIZE)
+    c.min_match_length = ZLIB_MIN_STRING_LENGTH
+    c.max_match_length = ZLIB_MAX_STRING_LENGTH
+    return c
+
+
+class HuffmanTree:
+    """The encoding side of zlib::huffman::HuffmanTree: a canonical code table
+    (symbol -> (LSB-first code, length)) as `assign` + `to_canonical` leave it."""
+
+    def __init__(self, table=None):
+        self._map = dict(table or {})
+
+    def encode(self, symbol: int) -> Optional[Tuple[int, int]]:
+        return self._map.get(int(symbol))
+
+    def encodings(self):
+        return dict(self._map)
+
+    def n_codes(self) -> int:
+        return len(self._map)
+
+    def max_code_len(self) -> int:
+        return max((l for _, l in self._map.values()), default=0)
+
+    @staticmethod
+    def from_lz77(units: Sequence, lz77: Optional[LZ77Compressor] = None, *, ctx: Optional[Context] = None):
+        """HuffmanTree::from_lz77(&units, &lz77) followed by assign + to_canonical on both trees
+        (create_dynamic_trees, src/compress.rs:296-314).  `lz77` must carry the zlib parameters
+        (check_lz77, src/huffman.rs:817-835)."""
+        if lz77 is not None:
+            if lz77.window_size != ZLIB_WINDOW_SIZE:
+                raise ValueError(f"Incompatible LZ77 window size, required {ZLIB_WINDOW_SIZE}, found {lz77.window_size}")
+            if lz77.min_match_length != ZLIB_MIN_STRING_LENGTH:
+                raise ValueError(f"Incompatible LZ77 min string length, required 3, found {lz77.min_match_length}")
+            if lz77.max_match_length != ZLIB_MAX_STRING_LENGTH:
+                raise ValueError(f"Incompatible LZ77 max string length, required 258, found {lz77.max_match_length}")
+        ctx = ctx or default_context()
+        toks = list(units)
+        if toks and not isinstance(toks[0], int):
+            toks = pack_units(toks)
+        arr = (C.c_uint32 * max(1, len(toks)))(*toks)
+        ll_len, d_len = (C.c_uint8 * 286)(), (C.c_uint8 * 30)()
+        ll_code, d_code = (C.c_uint16 * 286)(), (C.c_uint16 * 30)()
+        _check(_lib.lib().zg_huffman_from_tokens(ctx.handle, arr, len(toks), ll_len, ll_code, d_len, d_code), ctx)
+        lt = HuffmanTree({s: (ll_code[s], ll_len[s]) for s in range(286) if ll_len[s]})
+        dt = HuffmanTree({s: (d_code[s], d_len[s]) for s in range(30) if d_len[s]})
+        return lt, dt
+
+
+CORPUS_KINDS = {"text": 0, "random": 1, "binary": 2, "mixed": 3, "records": 4}
+
+
+def corpus(kind: str, n: int, seed: int = 0x5EED0001, offset: int = 0) -> bytes:
+    """Synthetic corpus bytes [offset, offset + n) (host-side generator)."""
+    buf = C.create_string_buffer(max(1, n))
+    rc = _lib.lib().zg_corpus_fill(CORPUS_KINDS[kind], seed, offset, C.cast(buf, C.c_void_p), n)
+    if rc:
+        raise ZgError(rc)
+    return buf.raw[:n]
+
+
+def corpus_into(kind: str, ptr: int, n: int, seed: int = 0x5EED0001, offset: int = 0):
+    """Fills host memory at `ptr` (e.g. a pinned torch tensor's data_ptr())."""
+    rc = _lib.lib().zg_corpus_fill(CORPUS_KINDS[kind], seed, offset, ptr, n)
+    if rc:
+        raise ZgError(rc)

@@ -1,0 +1,695 @@
+// Host orchestration and the C ABI (include/zlib_amd.h).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "zg_internal.h"
+
+using namespace zg;
+
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + (bytes >> 3) + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            want = bytes + 256;
+            e = hipMalloc(&p, want);
+        }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+enum KernelId { K_INDEX, K_MATCH, K_PARSE, K_HUFFMAN, K_TILEBITS, K_OFFSETS, K_ENCODE, K_ADLER, K_STORED, K_MISC, K_COUNT };
+const char *const kKernelNames[K_COUNT] = {"k_index", "k_match", "k_parse", "k_huffman", "k_tile_bits",
+                                           "k_offsets", "k_encode", "k_adler", "k_stored", "misc"};
+
+// device scalars
+struct Scalars {
+    uint64_t carry;       // absolute bit offset of the next block
+    uint64_t out_bytes;   // final size written by k_trailer
+    uint32_t adler[2];    // running a, b
+    uint32_t status;      // bit 0: output capacity exceeded
+    uint32_t pad;
+};
+
+}  // namespace
+
+struct zg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+    DevBuf far, next, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
+        scalars, stage_in, stage_out, misc;
+    // shard state kept between zg_shard_begin and zg_shard_finish
+    bool shard_active = false;
+    ChunkGrid shard_grid{};
+    int shard_strategy = 0;
+    uint32_t shard_max_tiles = 0;
+    uint64_t shard_total_bits = 0;
+    // profiling
+    bool prof = false;
+    struct Ev {
+        int id;
+        hipEvent_t a, b;
+    };
+    std::vector<Ev> events;
+    double prof_ms[K_COUNT] = {0};
+    uint64_t prof_n[K_COUNT] = {0};
+};
+
+namespace {
+
+zg_ctx *g_default = nullptr;
+std::mutex g_default_mu;
+
+int fail_hip(zg_ctx *c, hipError_t e, const char *what) {
+    c->err = std::string(what) + ": " + hipGetErrorString(e);
+    return ZG_ERR_HIP;
+}
+#define HIPCHK(call)                                          \
+    do {                                                      \
+        hipError_t e_ = (call);                               \
+        if (e_ != hipSuccess) return fail_hip(c, e_, #call);  \
+    } while (0)
+
+struct ProfScope {
+    zg_ctx *c;
+    int id;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(zg_ctx *c_, int id_) : c(c_), id(id_) {
+        if (c->prof && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+            (void)hipEventRecord(a, c->stream);
+    }
+    ~ProfScope() {
+        if (a && b) {
+            (void)hipEventRecord(b, c->stream);
+            c->events.push_back({id, a, b});
+        }
+    }
+};
+#define LAUNCH(id, call)           \
+    do {                           \
+        ProfScope ps_(c, id);      \
+        HIPCHK(call);              \
+    } while (0)
+
+void prof_collect(zg_ctx *c) {
+    for (auto &e : c->events) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            c->prof_ms[e.id] += ms;
+            c->prof_n[e.id] += 1;
+        }
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    c->events.clear();
+}
+
+struct Plan {
+    size_t chunk_bytes;
+    size_t batch_chunks;
+};
+int make_plan(const zg_opts *opts, Plan *p) {
+    size_t cb = (opts && opts->chunk_bytes) ? opts->chunk_bytes : ((size_t)1 << 20);
+    size_t bb = (opts && opts->batch_bytes) ? opts->batch_bytes : ((size_t)256 << 20);
+    if (cb < 1024 || (cb % 1024) != 0 || cb > ((size_t)1 << 30)) return ZG_ERR_ARG;
+    size_t bc = bb / cb;
+    if (bc < 1) bc = 1;
+    if (bc > 32768) bc = 32768;
+    p->chunk_bytes = cb;
+    p->batch_chunks = bc;
+    return ZG_OK;
+}
+
+uint32_t max_tiles_for(size_t chunk_bytes) { return (uint32_t)((chunk_bytes + 1 + kEncTile - 1) / kEncTile); }
+
+// Strategy::Auto (reference src/compress.rs:89-169): decided on the host from the first KiB.  The entropy
+// sum runs in ascending symbol order (the reference follows HashMap order) and heuristic 2 sums the five
+// smallest counts, as the reference code does.
+int auto_choice(const uint8_t *head, size_t n) {
+    if (n < 256) return ZG_RAW;
+    if (n < 1024) return ZG_FIXED;
+    size_t freq[256] = {0};
+    for (size_t i = 0; i < 1024; i++) freq[head[i]]++;
+    double ent = 0.0, preference = 0.0;
+    size_t distinct = 0;
+    std::vector<uint32_t> counts;
+    for (int s = 0; s < 256; s++)
+        if (freq[s]) {
+            const double p = (double)freq[s] / 1024.0;
+            ent += p * std::log2(p);
+            distinct++;
+            counts.push_back((uint32_t)freq[s]);
+        }
+    const double proximity = 1.0 - std::fabs((-ent / std::log2((double)distinct)) - 1.0);
+    preference += proximity > 0.75 ? proximity : 0.5 * proximity;
+    std::sort(counts.begin(), counts.end());
+    uint32_t sum = 0;
+    for (size_t i = 0; i < std::min<size_t>(5, counts.size()); i++) sum += counts[i];
+    const double proportion = (double)sum / 1024.0;
+    preference -= proportion > 0.5 ? proportion : 0.5 * proportion;
+    if (preference > 0.1) return ZG_FIXED;
+    if (preference < -0.1) return ZG_DYNAMIC;
+    const double ratio = (double)distinct * std::log2((double)n) / (double)n;
+    return ratio < 0.5 ? ZG_DYNAMIC : ZG_FIXED;
+}
+
+int ensure_chunk_meta(zg_ctx *c, size_t nc, uint32_t max_tiles) {
+    HIPCHK(c->ntok.ensure(nc * sizeof(uint32_t)));
+    HIPCHK(c->freq.ensure(nc * kTabStride * sizeof(uint32_t)));
+    HIPCHK(c->tab.ensure(nc * kTabStride * sizeof(uint32_t)));
+    HIPCHK(c->hdr.ensure(nc * kHdrWords * sizeof(uint32_t)));
+    HIPCHK(c->hdr_bits.ensure(nc * sizeof(uint32_t)));
+    HIPCHK(c->block_bits.ensure(nc * sizeof(uint64_t)));
+    HIPCHK(c->bit_off.ensure(nc * sizeof(uint64_t)));
+    HIPCHK(c->tile_bits.ensure(nc * (size_t)max_tiles * sizeof(uint32_t)));
+    return ZG_OK;
+}
+
+// index + match + parse + code construction for chunks [c0, c1) of the grid
+int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, int strategy,
+              int64_t final_chunk, bool want_codes) {
+    const uint64_t bs = g.first + (uint64_t)c0 * g.chunk_bytes;
+    const uint64_t be = std::min<uint64_t>(g.end, g.first + (uint64_t)c1 * g.chunk_bytes);
+    const uint64_t ib0 = (bs > mp.window ? bs - mp.window : 0) & ~(uint64_t)15;  // scratch arrays start here
+    const uint64_t span = be - ib0;
+    HIPCHK(c->far.ensure(span * 2 + 64));
+    HIPCHK(c->next.ensure(span * 2 + 64));
+    HIPCHK(c->match.ensure(span * 4 + 64));
+    HIPCHK(c->tokens.ensure((be - bs) * 4 + 64));
+    if (span) {
+        LAUNCH(K_MISC, hipMemsetAsync(c->next.p, 0, span * 2, c->stream));
+        LAUNCH(K_INDEX, launch_index(g.data, g.end, ib0, be, bs, mp.window, c->far.as<uint16_t>(),
+                                     c->next.as<uint16_t>(), ib0, c->stream));
+        LAUNCH(K_MATCH, launch_match(g, c0, c1, mp, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
+                                     c->match.as<uint32_t>(), c->stream));
+    }
+    LAUNCH(K_PARSE, launch_parse(g, c0, c1, c->match.as<uint32_t>(), ib0, c->tokens.as<uint32_t>(), bs,
+                                 c->ntok.as<uint32_t>(), c->freq.as<uint32_t>(), c->stream));
+    if (want_codes)
+        LAUNCH(K_HUFFMAN, launch_huffman(c1 - c0, strategy, c->freq.as<uint32_t>(), final_chunk, c->tab.as<uint32_t>(),
+                                         c->hdr.as<uint32_t>(), c->hdr_bits.as<uint32_t>(),
+                                         c->block_bits.as<uint64_t>(), c->stream));
+    return ZG_OK;
+}
+
+// bit offsets + packing for chunks [c0, c1); the carry scalar holds the first block's bit offset
+int run_back(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, uint32_t max_tiles, uint32_t *out,
+             uint64_t out_cap_bits) {
+    Scalars *sc = c->scalars.as<Scalars>();
+    const uint64_t bs = g.first + (uint64_t)c0 * g.chunk_bytes;
+    LAUNCH(K_TILEBITS, launch_tile_bits(c1 - c0, max_tiles, c->tokens.as<uint32_t>(), g, c0, bs,
+                                        c->ntok.as<uint32_t>(), c->tab.as<uint32_t>(), c->tile_bits.as<uint32_t>(),
+                                        c->stream));
+    LAUNCH(K_OFFSETS, launch_offsets(c1 - c0, max_tiles, c->ntok.as<uint32_t>(), c->tile_bits.as<uint32_t>(),
+                                     c->block_bits.as<uint64_t>(), c->bit_off.as<uint64_t>(), &sc->carry, c->stream));
+    LAUNCH(K_ENCODE, launch_encode(c1 - c0, max_tiles, c->tokens.as<uint32_t>(), g, c0, bs, c->ntok.as<uint32_t>(),
+                                   c->tab.as<uint32_t>(), c->hdr.as<uint32_t>(), c->hdr_bits.as<uint32_t>(),
+                                   c->tile_bits.as<uint32_t>(), c->bit_off.as<uint64_t>(), out, out_cap_bits,
+                                   &sc->status, c->stream));
+    return ZG_OK;
+}
+
+// Adler-32 of data[0..n) folded into the running state
+int run_adler(zg_ctx *c, const uint8_t *data, uint64_t n) {
+    if (!n) return ZG_OK;
+    const uint64_t seg = 256 * 1024;
+    Scalars *sc = c->scalars.as<Scalars>();
+    const uint64_t nseg = (n + seg - 1) / seg;
+    HIPCHK(c->adler_part.ensure(nseg * 2 * sizeof(uint32_t)));
+    LAUNCH(K_ADLER, launch_adler(data, n, seg, (uint32_t)nseg, c->adler_part.as<uint32_t>(), c->stream));
+    LAUNCH(K_ADLER, launch_adler_fold(c->adler_part.as<uint32_t>(), n, seg, (uint32_t)nseg, sc->adler, c->stream));
+    return ZG_OK;
+}
+
+int init_scalars(zg_ctx *c, uint64_t carry) {
+    HIPCHK(c->scalars.ensure(sizeof(Scalars)));
+    Scalars h{};
+    h.carry = carry;
+    h.adler[0] = 1;
+    h.adler[1] = 0;
+    HIPCHK(hipMemcpyAsync(c->scalars.p, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // h is a stack object
+    return ZG_OK;
+}
+
+size_t stored_size(size_t n) {
+    const size_t nb = n == 0 ? 1 : (n + kStoredBlock - 1) / kStoredBlock;
+    return 2 + n + 5 * nb + 4;
+}
+
+int compress_device_locked(zg_ctx *c, const uint8_t *d_in, size_t n, int strategy, const zg_opts *opts,
+                           uint8_t *d_out, size_t out_cap, size_t *out_n) {
+    Plan plan;
+    int rc = make_plan(opts, &plan);
+    if (rc) return rc;
+    if (strategy < ZG_AUTO || strategy > ZG_RAW) return ZG_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(d_out) & 3) != 0) return ZG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (strategy == ZG_AUTO) {
+        uint8_t head[1024];
+        const size_t hn = std::min<size_t>(n, 1024);
+        if (hn) HIPCHK(hipMemcpy(head, d_in, hn, hipMemcpyDeviceToHost));
+        strategy = auto_choice(head, n);
+    }
+    if (out_cap < zg_compress_bound(n, strategy, opts)) return ZG_ERR_CAPACITY;
+    rc = init_scalars(c, 16);
+    if (rc) return rc;
+    Scalars *sc = c->scalars.as<Scalars>();
+
+    if (strategy == ZG_RAW) {
+        LAUNCH(K_STORED, launch_stored(d_in, n, d_out, c->stream));
+        rc = run_adler(c, d_in, n);
+        if (rc) return rc;
+        const uint64_t bits = (uint64_t)(stored_size(n) - 4) * 8;
+        HIPCHK(hipMemcpyAsync(&sc->carry, &bits, sizeof bits, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        LAUNCH(K_MISC, launch_trailer(d_out, &sc->carry, sc->adler, 0, 0, 1, 1, &sc->out_bytes, c->stream));
+    } else {
+        ChunkGrid g;
+        g.data = d_in;
+        g.first = 0;
+        g.end = n;
+        g.chunk_bytes = plan.chunk_bytes;
+        g.n_chunks = n == 0 ? 1u : (uint32_t)((n + plan.chunk_bytes - 1) / plan.chunk_bytes);
+        const uint32_t max_tiles = max_tiles_for(plan.chunk_bytes);
+        const size_t bc = std::min<size_t>(plan.batch_chunks, g.n_chunks);
+        rc = ensure_chunk_meta(c, bc, max_tiles);
+        if (rc) return rc;
+        const size_t bound = zg_compress_bound(n, strategy, opts);
+        LAUNCH(K_MISC, hipMemsetAsync(d_out, 0, bound, c->stream));
+        const MatchParams mp{kMaxWindow, 3, 258};  // get_zlib_compressor, src/compress.rs:451-456
+        for (uint32_t c0 = 0; c0 < g.n_chunks; c0 += (uint32_t)bc) {
+            const uint32_t c1 = (uint32_t)std::min<uint64_t>(g.n_chunks, (uint64_t)c0 + bc);
+            const int64_t final_chunk = (c1 == g.n_chunks) ? (int64_t)(c1 - c0 - 1) : -1;
+            rc = run_front(c, g, c0, c1, mp, strategy, final_chunk, true);
+            if (rc) return rc;
+            rc = run_back(c, g, c0, c1, max_tiles, reinterpret_cast<uint32_t *>(d_out), (uint64_t)(bound - 4) * 8);
+            if (rc) return rc;
+        }
+        rc = run_adler(c, d_in, n);
+        if (rc) return rc;
+        LAUNCH(K_MISC, launch_trailer(d_out, &sc->carry, sc->adler, 0, 0, 1, 1, &sc->out_bytes, c->stream));
+    }
+    Scalars h;
+    HIPCHK(hipMemcpyAsync(&h, c->scalars.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->prof) prof_collect(c);
+    if (h.status & 1u) return ZG_ERR_CAPACITY;
+    *out_n = (size_t)h.out_bytes;
+    return ZG_OK;
+}
+
+zg_ctx *resolve(zg_ctx *ctx, int *rc) {
+    if (ctx) return ctx;
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (!g_default) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        *rc = zg_init(dev, &g_default);
+        if (*rc) g_default = nullptr;
+    }
+    return g_default;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zg_init(int device, zg_ctx **ctx) {
+    if (!ctx) return ZG_ERR_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+        return ZG_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return ZG_ERR_NO_DEVICE;
+    zg_ctx *c = new (std::nothrow) zg_ctx();
+    if (!c) return ZG_ERR_NOMEM;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return ZG_ERR_NO_DEVICE;
+    }
+    *ctx = c;
+    return ZG_OK;
+}
+
+void zg_destroy(zg_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    DevBuf *bufs[] = {&c->far, &c->next, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
+                      &c->block_bits, &c->bit_off, &c->tile_bits, &c->adler_part, &c->scalars, &c->stage_in,
+                      &c->stage_out, &c->misc};
+    for (DevBuf *b : bufs) b->release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *zg_strerror(int code) {
+    switch (code) {
+    case ZG_OK: return "ok";
+    case ZG_ERR_ARG: return "invalid argument";
+    case ZG_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU path)";
+    case ZG_ERR_HIP: return "HIP runtime call failed";
+    case ZG_ERR_NOMEM: return "out of memory";
+    case ZG_ERR_CAPACITY: return "output buffer too small";
+    case ZG_ERR_UNSUPPORTED: return "parameters not supported by the device path";
+    case ZG_ERR_INTERNAL: return "internal consistency check failed";
+    default: return "unknown error";
+    }
+}
+
+const char *zg_last_error(zg_ctx *ctx) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    return c ? c->err.c_str() : "no context";
+}
+
+void zg_free(void *p) { free(p); }
+
+size_t zg_compress_bound(size_t n, int strategy, const zg_opts *opts) {
+    Plan plan;
+    if (make_plan(opts, &plan)) return 0;
+    if (strategy == ZG_RAW) return (stored_size(n) + 3) & ~(size_t)3;
+    // worst case per unit: a 15-bit literal code; per block: header of at most kHdrWords words + EOB.
+    // Auto may resolve to Raw, so take the larger of the two.
+    const size_t nchunks = n == 0 ? 1 : (n + plan.chunk_bytes - 1) / plan.chunk_bytes;
+    size_t bits_bytes = 2 + (n * 15 + 7) / 8 + nchunks * (kHdrWords * 4 + 2) + 4 + 8;
+    if (strategy == ZG_AUTO) bits_bytes = std::max(bits_bytes, stored_size(n));
+    return (bits_bytes + 3) & ~(size_t)3;
+}
+
+int zg_compress_device(zg_ctx *ctx, const void *d_in, size_t n, int strategy, const zg_opts *opts, void *d_out,
+                       size_t out_cap, size_t *out_n) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (!d_out || !out_n || (!d_in && n)) return ZG_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return compress_device_locked(c, static_cast<const uint8_t *>(d_in), n, strategy, opts,
+                                  static_cast<uint8_t *>(d_out), out_cap, out_n);
+}
+
+int zg_compress(zg_ctx *ctx, const uint8_t *in, size_t n, int strategy, const zg_opts *opts, uint8_t **out,
+                size_t *out_n) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (!out || !out_n || (!in && n)) return ZG_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    if (strategy == ZG_AUTO) strategy = auto_choice(in, n);
+    const size_t bound = zg_compress_bound(n, strategy, opts);
+    if (!bound) return ZG_ERR_ARG;
+    HIPCHK(c->stage_in.ensure(n + 64));
+    HIPCHK(c->stage_out.ensure(bound));
+    if (n) HIPCHK(hipMemcpyAsync(c->stage_in.p, in, n, hipMemcpyHostToDevice, c->stream));
+    size_t got = 0;
+    rc = compress_device_locked(c, c->stage_in.as<uint8_t>(), n, strategy, opts, c->stage_out.as<uint8_t>(), bound,
+                                &got);
+    if (rc) return rc;
+    uint8_t *h = static_cast<uint8_t *>(malloc(got ? got : 1));
+    if (!h) return ZG_ERR_NOMEM;
+    HIPCHK(hipMemcpy(h, c->stage_out.p, got, hipMemcpyDeviceToHost));
+    *out = h;
+    *out_n = got;
+    return ZG_OK;
+}
+
+uint32_t zg_adler32_combine(uint32_t adler1, uint32_t adler2, uint64_t len2) {
+    const uint64_t M = 65521;
+    const uint64_t a1 = adler1 & 0xFFFF, b1 = adler1 >> 16, a2 = adler2 & 0xFFFF, b2 = adler2 >> 16;
+    const uint64_t a = (a1 + a2 + M - 1) % M;
+    const uint64_t b = (b1 + b2 + (len2 % M) * ((a1 + M - 1) % M)) % M;
+    return (uint32_t)(b << 16 | a);
+}
+
+int zg_adler32_device(zg_ctx *ctx, const void *d_in, size_t n, uint32_t *out) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (!out || (!d_in && n)) return ZG_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    rc = init_scalars(c, 0);
+    if (rc) return rc;
+    rc = run_adler(c, static_cast<const uint8_t *>(d_in), n);
+    if (rc) return rc;
+    Scalars h;
+    HIPCHK(hipMemcpyAsync(&h, c->scalars.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->prof) prof_collect(c);
+    *out = (h.adler[1] << 16) | h.adler[0];
+    return ZG_OK;
+}
+
+int zg_adler32(zg_ctx *ctx, const uint8_t *in, size_t n, uint32_t *out) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (!out || (!in && n)) return ZG_ERR_ARG;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(c->stage_in.ensure(n + 64));
+        if (n) HIPCHK(hipMemcpyAsync(c->stage_in.p, in, n, hipMemcpyHostToDevice, c->stream));
+    }
+    return zg_adler32_device(c, c->stage_in.p, n, out);
+}
+
+int zg_lz77(zg_ctx *ctx, const uint8_t *in, size_t n, size_t start, uint32_t window, uint32_t min_len,
+            uint32_t max_len, uint32_t **tokens, size_t *n_tokens) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (!tokens || !n_tokens || (!in && n) || start > n) return ZG_ERR_ARG;
+    if (min_len < 3 || max_len > kMaxMatch) return ZG_ERR_UNSUPPORTED;
+    if (window > kMaxWindow) window = kMaxWindow;  // with_window_size / set_window_size clamp, src/lz77.rs:90-120
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(c->stage_in.ensure(n + 64));
+    if (n) HIPCHK(hipMemcpyAsync(c->stage_in.p, in, n, hipMemcpyHostToDevice, c->stream));
+    ChunkGrid g;
+    g.data = c->stage_in.as<uint8_t>();
+    g.first = start;
+    g.end = n;
+    g.chunk_bytes = std::max<uint64_t>(n - start, 1);
+    g.n_chunks = 1;
+    rc = ensure_chunk_meta(c, 1, 1);
+    if (rc) return rc;
+    rc = run_front(c, g, 0, 1, MatchParams{window, min_len, max_len}, ZG_DYNAMIC, -1, false);
+    if (rc) return rc;
+    uint32_t nt = 0;
+    HIPCHK(hipMemcpyAsync(&nt, c->ntok.p, sizeof nt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint32_t *h = static_cast<uint32_t *>(malloc((nt ? nt : 1) * sizeof(uint32_t)));
+    if (!h) return ZG_ERR_NOMEM;
+    if (nt) HIPCHK(hipMemcpy(h, c->tokens.p, (size_t)nt * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (c->prof) prof_collect(c);
+    *tokens = h;
+    *n_tokens = nt;
+    return ZG_OK;
+}
+
+int zg_huffman_from_tokens(zg_ctx *ctx, const uint32_t *tokens, size_t n, uint8_t ll_len[286], uint16_t ll_code[286],
+                           uint8_t d_len[30], uint16_t d_code[30]) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if ((!tokens && n) || !ll_len || !ll_code || !d_len || !d_code) return ZG_ERR_ARG;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t t = tokens[i];
+        if (ZG_TOK_IS_MARKER(t)) {
+            if (ZG_TOK_LEN(t) < 3 || ZG_TOK_LEN(t) > 258 || ZG_TOK_DIST(t) < 1 || ZG_TOK_DIST(t) > 32768)
+                return ZG_ERR_ARG;  // asserts of length_writer / distance_writer, src/compress.rs:325-326,355-356
+        } else if (t > 255) {
+            return ZG_ERR_ARG;
+        }
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(c->misc.ensure(n * sizeof(uint32_t) + 64));
+    rc = ensure_chunk_meta(c, 1, 1);
+    if (rc) return rc;
+    if (n) HIPCHK(hipMemcpyAsync(c->misc.p, tokens, n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    LAUNCH(K_PARSE, launch_histogram(c->misc.as<uint32_t>(), n, c->freq.as<uint32_t>(), c->stream));
+    LAUNCH(K_HUFFMAN, launch_huffman(1, ZG_DYNAMIC, c->freq.as<uint32_t>(), 0, c->tab.as<uint32_t>(),
+                                     c->hdr.as<uint32_t>(), c->hdr_bits.as<uint32_t>(), c->block_bits.as<uint64_t>(),
+                                     c->stream));
+    uint32_t tab[kTabStride];
+    HIPCHK(hipMemcpyAsync(tab, c->tab.p, sizeof tab, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->prof) prof_collect(c);
+    for (int i = 0; i < 286; i++) {
+        ll_len[i] = (uint8_t)(tab[i] >> 16);
+        ll_code[i] = (uint16_t)(tab[i] & 0xFFFF);
+    }
+    for (int i = 0; i < 30; i++) {
+        d_len[i] = (uint8_t)(tab[kDOff + i] >> 16);
+        d_code[i] = (uint16_t)(tab[kDOff + i] & 0xFFFF);
+    }
+    return ZG_OK;
+}
+
+int zg_shard_begin(zg_ctx *ctx, const void *d_in, size_t halo, size_t n, int strategy, const zg_opts *opts,
+                   int last_rank, zg_shard_info *info) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (!info || (!d_in && (n || halo)) || halo > kMaxWindow) return ZG_ERR_ARG;
+    if (strategy != ZG_DYNAMIC && strategy != ZG_FIXED) return ZG_ERR_UNSUPPORTED;
+    Plan plan;
+    rc = make_plan(opts, &plan);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    c->shard_active = false;
+    ChunkGrid g;
+    g.data = static_cast<const uint8_t *>(d_in);
+    g.first = halo;
+    g.end = halo + n;
+    g.chunk_bytes = plan.chunk_bytes;
+    g.n_chunks = n == 0 ? 1u : (uint32_t)((n + plan.chunk_bytes - 1) / plan.chunk_bytes);
+    if (g.n_chunks > 65535) return ZG_ERR_UNSUPPORTED;
+    const uint32_t max_tiles = max_tiles_for(plan.chunk_bytes);
+    rc = ensure_chunk_meta(c, g.n_chunks, max_tiles);
+    if (rc) return rc;
+    rc = init_scalars(c, 0);
+    if (rc) return rc;
+    Scalars *sc = c->scalars.as<Scalars>();
+    const MatchParams mp{kMaxWindow, 3, 258};
+    rc = run_front(c, g, 0, g.n_chunks, mp, strategy, last_rank ? (int64_t)g.n_chunks - 1 : -1, true);
+    if (rc) return rc;
+    // total bits of the rank's blocks: the block-offset scan with a zero carry
+    LAUNCH(K_TILEBITS, launch_tile_bits(g.n_chunks, max_tiles, c->tokens.as<uint32_t>(), g, 0, g.first,
+                                        c->ntok.as<uint32_t>(), c->tab.as<uint32_t>(), c->tile_bits.as<uint32_t>(),
+                                        c->stream));
+    LAUNCH(K_OFFSETS, launch_offsets(g.n_chunks, max_tiles, c->ntok.as<uint32_t>(), c->tile_bits.as<uint32_t>(),
+                                     c->block_bits.as<uint64_t>(), c->bit_off.as<uint64_t>(), &sc->carry, c->stream));
+    rc = run_adler(c, g.data + halo, n);
+    if (rc) return rc;
+    Scalars h;
+    HIPCHK(hipMemcpyAsync(&h, c->scalars.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    info->total_bits = h.carry;
+    info->adler = (h.adler[1] << 16) | h.adler[0];
+    info->n_chunks = g.n_chunks;
+    c->shard_grid = g;
+    c->shard_strategy = strategy;
+    c->shard_max_tiles = max_tiles;
+    c->shard_total_bits = h.carry;
+    c->shard_active = true;
+    return ZG_OK;
+}
+
+// The block offsets computed in zg_shard_begin are relative to bit 0; finish shifts them by the rank's
+// start bit inside d_out.
+namespace {
+__global__ void k_shift_offsets(uint64_t *bit_off, uint32_t n, uint64_t delta) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) bit_off[i] += delta;
+}
+}  // namespace
+
+int zg_shard_finish(zg_ctx *ctx, uint64_t base_bit, int first_rank, int last_rank, uint32_t adler, void *d_out,
+                    size_t out_cap, size_t *out_bytes) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (!d_out || !out_bytes || (reinterpret_cast<uintptr_t>(d_out) & 3)) return ZG_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->shard_active) return ZG_ERR_ARG;
+    if (first_rank && base_bit != 16) return ZG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const ChunkGrid &g = c->shard_grid;
+    Scalars *sc = c->scalars.as<Scalars>();
+    const uint64_t local0 = first_rank ? 16 : (base_bit & 7);  // bit offset of the first block inside d_out
+    const uint64_t end_bit = local0 + c->shard_total_bits;
+    const uint64_t need = ((end_bit + 7) >> 3) + (last_rank ? 4 : 0);
+    if (out_cap < ((need + 3) & ~(uint64_t)3)) return ZG_ERR_CAPACITY;
+    LAUNCH(K_MISC, hipMemsetAsync(d_out, 0, (need + 3) & ~(uint64_t)3, c->stream));
+    {
+        ProfScope ps(c, K_OFFSETS);
+        hipLaunchKernelGGL(k_shift_offsets, dim3((g.n_chunks + 255) / 256), dim3(256), 0, c->stream,
+                           c->bit_off.as<uint64_t>(), g.n_chunks, local0);
+        HIPCHK(hipGetLastError());
+    }
+    LAUNCH(K_ENCODE, launch_encode(g.n_chunks, c->shard_max_tiles, c->tokens.as<uint32_t>(), g, 0, g.first,
+                                   c->ntok.as<uint32_t>(), c->tab.as<uint32_t>(), c->hdr.as<uint32_t>(),
+                                   c->hdr_bits.as<uint32_t>(), c->tile_bits.as<uint32_t>(), c->bit_off.as<uint64_t>(),
+                                   static_cast<uint32_t *>(d_out), (uint64_t)(((need + 3) & ~(uint64_t)3)) * 8,
+                                   &sc->status, c->stream));
+    HIPCHK(hipMemcpyAsync(&sc->carry, &end_bit, sizeof end_bit, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    LAUNCH(K_MISC, launch_trailer(static_cast<uint8_t *>(d_out), &sc->carry, sc->adler, adler, 1, first_rank ? 1 : 0,
+                                  last_rank ? 1 : 0, &sc->out_bytes, c->stream));
+    Scalars h;
+    HIPCHK(hipMemcpyAsync(&h, c->scalars.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->prof) prof_collect(c);
+    c->shard_active = false;
+    if (h.status & 1u) return ZG_ERR_CAPACITY;
+    *out_bytes = (size_t)h.out_bytes;
+    return ZG_OK;
+}
+
+int zg_profile_enable(zg_ctx *ctx, int on) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->prof = on != 0;
+    return ZG_OK;
+}
+int zg_profile_reset(zg_ctx *ctx) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (int i = 0; i < K_COUNT; i++) {
+        c->prof_ms[i] = 0;
+        c->prof_n[i] = 0;
+    }
+    return ZG_OK;
+}
+int zg_profile_count(zg_ctx *) { return K_COUNT; }
+int zg_profile_get(zg_ctx *ctx, int index, const char **name, double *ms, uint64_t *launches) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (index < 0 || index >= K_COUNT) return ZG_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (name) *name = kKernelNames[index];
+    if (ms) *ms = c->prof_ms[index];
+    if (launches) *launches = c->prof_n[index];
+    return ZG_OK;
+}
+
+}  // extern "C"

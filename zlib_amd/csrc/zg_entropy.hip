@@ -1,0 +1,452 @@
+// Everything between the per-position match table and the packed bit stream:
+// greedy parse resolution + token emission + literal/length/distance
+// histograms (k_parse), per-block code construction (k_huffman), and the
+// prefix-sum / scatter-pack bit writer (k_tile_bits, k_offsets, k_encode).
+#include "zg_huff_core.h"
+#include "zg_internal.h"
+
+namespace zg {
+
+// ---------------------------------------------------------------------------
+// k_parse: one workgroup per chunk.  The greedy parse of
+// LZ77Compressor::compress (reference src/lz77.rs:156-204) is the chain
+// pos -> pos + max(1, L(pos)); it is walked tile by tile in LDS, then all
+// threads turn the visited positions into packed LZ77 units (in order, by a
+// block-wide prefix sum of the visit flags) and count symbols with LDS
+// atomics as HuffmanTree::from_lz77 does (src/huffman.rs:243-264).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kParseThreads) void k_parse(const uint8_t *__restrict__ data, uint64_t first,
+                                                          uint64_t end, uint64_t chunk_bytes, uint32_t c0,
+                                                          const uint32_t *__restrict__ match, uint64_t base,
+                                                          uint32_t *__restrict__ tokens, uint64_t tok_base,
+                                                          uint32_t *__restrict__ ntok, uint32_t *__restrict__ freq) {
+    __shared__ uint32_t s_m[kParseTile];
+    __shared__ uint8_t s_flag[kParseTile];
+    __shared__ uint32_t s_hist[kTabStride];
+    __shared__ uint32_t s_scan[kParseThreads];
+    __shared__ uint64_t s_entry;
+    __shared__ uint32_t s_ntok;
+
+    const uint32_t ci = blockIdx.x;  // index inside the batch
+    const uint32_t chunk = c0 + ci;
+    const uint64_t cs = first + (uint64_t)chunk * chunk_bytes;
+    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+    const uint32_t tid = threadIdx.x;
+    uint32_t *tok_out = tokens + (cs - tok_base);
+
+    for (uint32_t i = tid; i < kTabStride; i += kParseThreads) s_hist[i] = 0;
+    if (tid == 0) {
+        s_entry = cs;
+        s_ntok = 0;
+    }
+    __syncthreads();
+
+    constexpr uint32_t kPer = kParseTile / kParseThreads;  // consecutive positions per thread
+    for (uint64_t tile0 = cs; tile0 < ce; tile0 += kParseTile) {
+        const uint32_t tn = (uint32_t)((ce - tile0 < kParseTile) ? ce - tile0 : kParseTile);
+        for (uint32_t i = tid; i < tn; i += kParseThreads) {
+            s_m[i] = match[tile0 + i - base];
+            s_flag[i] = 0;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint64_t rel = s_entry - tile0;  // may already lie past this tile
+            while (rel < tn) {
+                s_flag[rel] = 1;
+                const uint32_t len = s_m[rel] >> 16;
+                rel += len ? len : 1u;
+            }
+            s_entry = tile0 + rel;
+        }
+        __syncthreads();
+        const uint32_t b0 = tid * kPer;
+        uint32_t cnt = 0;
+        for (uint32_t i = 0; i < kPer; i++)
+            if (b0 + i < tn) cnt += s_flag[b0 + i];
+        s_scan[tid] = cnt;
+        __syncthreads();
+        for (uint32_t off = 1; off < kParseThreads; off <<= 1) {  // inclusive Hillis-Steele scan
+            const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        uint32_t o = s_ntok + s_scan[tid] - cnt;
+        for (uint32_t i = 0; i < kPer; i++) {
+            const uint32_t r = b0 + i;
+            if (r < tn && s_flag[r]) {
+                const uint32_t mv = s_m[r];
+                uint32_t tok;
+                if (mv) {
+                    const uint32_t len = mv >> 16, dist = mv & 0xFFFFu;
+                    tok = ZG_TOK_MARKER | (len << 16) | dist;
+                    atomicAdd(&s_hist[257u + length_code_index(len)], 1u);
+                    atomicAdd(&s_hist[kDOff + dist_code(dist)], 1u);
+                } else {
+                    tok = data[tile0 + r];
+                    atomicAdd(&s_hist[tok], 1u);
+                }
+                tok_out[o++] = tok;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_ntok += s_scan[kParseThreads - 1];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        ntok[ci] = s_ntok;
+        if (s_hist[256] == 0) s_hist[256] = 1;  // "ensure terminating character is encoded", huffman.rs:264
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < kTabStride; i += kParseThreads) freq[(uint64_t)ci * kTabStride + i] = s_hist[i];
+}
+
+hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint32_t *match, uint64_t base,
+                        uint32_t *tokens, uint64_t tok_base, uint32_t *ntok, uint32_t *freq, hipStream_t s) {
+    if (c1 <= c0) return hipSuccess;
+    hipLaunchKernelGGL(k_parse, dim3(c1 - c0), dim3(kParseThreads), 0, s, g.data, g.first, g.end, g.chunk_bytes, c0,
+                       match, base, tokens, tok_base, ntok, freq);
+    return hipGetLastError();
+}
+
+// Histogram of an existing token stream (used by zg_huffman_from_tokens).
+__global__ __launch_bounds__(256) void k_histogram(const uint32_t *__restrict__ tokens, uint64_t n,
+                                                    uint32_t *__restrict__ freq) {
+    __shared__ uint32_t s_hist[kTabStride];
+    for (uint32_t i = threadIdx.x; i < kTabStride; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t t = tokens[i];
+        if (ZG_TOK_IS_MARKER(t)) {
+            atomicAdd(&s_hist[257u + length_code_index(ZG_TOK_LEN(t))], 1u);
+            atomicAdd(&s_hist[kDOff + dist_code(ZG_TOK_DIST(t))], 1u);
+        } else {
+            atomicAdd(&s_hist[t & 0xFFu], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kTabStride; i += 256)
+        if (s_hist[i]) atomicAdd(&freq[i], s_hist[i]);
+}
+__global__ void k_histogram_finish(uint32_t *freq) {
+    if (threadIdx.x == 0 && freq[256] == 0) freq[256] = 1;
+}
+hipError_t launch_histogram(const uint32_t *tokens, uint64_t n, uint32_t *freq, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(freq, 0, kTabStride * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    if (n) {
+        uint32_t blocks = (uint32_t)((n + 255) / 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(k_histogram, dim3(blocks), dim3(256), 0, s, tokens, n, freq);
+    }
+    hipLaunchKernelGGL(k_histogram_finish, dim3(1), dim3(64), 0, s, freq);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// k_huffman: one wave per chunk; lane 0 runs the block builder over LDS.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_huffman(uint32_t n_chunks, int strategy, const uint32_t *__restrict__ freq,
+                                                 int64_t final_chunk, uint32_t *__restrict__ tab,
+                                                 uint32_t *__restrict__ hdr, uint32_t *__restrict__ hdr_bits,
+                                                 uint64_t *__restrict__ block_bits) {
+    __shared__ uint32_t s_freq[kTabStride];
+    __shared__ BlockTables s_tab;
+    __shared__ uint32_t s_hdr[kHdrWords];
+    __shared__ HeaderWork s_work;
+    __shared__ uint32_t s_hbits;
+    __shared__ uint64_t s_payload;
+
+    const uint32_t c = blockIdx.x;
+    if (c >= n_chunks) return;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < kTabStride; i += 64) s_freq[i] = freq[(uint64_t)c * kTabStride + i];
+    for (uint32_t i = lane; i < kHdrWords; i += 64) s_hdr[i] = 0;
+    __syncthreads();
+    if (lane == 0) {
+        uint64_t payload = 0;
+        s_hbits = build_block(s_freq, s_freq + kDOff, strategy, (int64_t)c == final_chunk, s_tab, s_hdr, &payload,
+                              s_work);
+        s_payload = payload;
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < kHuffMaxSyms; i += 64) tab[(uint64_t)c * kTabStride + i] = s_tab.ll[i];
+    if (lane < 32) tab[(uint64_t)c * kTabStride + kDOff + lane] = s_tab.d[lane];
+    for (uint32_t i = lane; i < kHdrWords; i += 64) hdr[(uint64_t)c * kHdrWords + i] = s_hdr[i];
+    if (lane == 0) {
+        hdr_bits[c] = s_hbits;
+        block_bits[c] = (uint64_t)s_hbits + s_payload;
+    }
+}
+
+hipError_t launch_huffman(uint32_t n_chunks, int strategy, const uint32_t *freq, int64_t final_chunk, uint32_t *tab,
+                          uint32_t *hdr, uint32_t *hdr_bits, uint64_t *block_bits, hipStream_t s) {
+    if (!n_chunks) return hipSuccess;
+    hipLaunchKernelGGL(k_huffman, dim3(n_chunks), dim3(64), 0, s, n_chunks, strategy, freq, final_chunk, tab, hdr,
+                       hdr_bits, block_bits);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Bit writer.  A chunk's units (plus one virtual end-of-block unit) are cut
+// into tiles of kEncTile; k_tile_bits sums the coded length of each tile,
+// k_offsets turns the sums into exclusive offsets per chunk and the block
+// lengths into absolute bit offsets, k_encode packs every unit at its offset.
+// What is written equals write_compressed_data (src/compress.rs:276-374)
+// through BitWriter::write_bits (src/bitwriter.rs:90-98).
+// ---------------------------------------------------------------------------
+struct Coded {
+    uint64_t bits;  // LSB-first payload
+    uint32_t n;     // number of bits (<= 48)
+};
+__device__ __forceinline__ Coded code_unit(uint32_t tok, const uint32_t *ll, const uint32_t *dt) {
+    Coded c;
+    if (!ZG_TOK_IS_MARKER(tok)) {  // literal_writer
+        const uint32_t t = ll[tok & 0x1FFu];
+        c.bits = t & 0xFFFFu;
+        c.n = t >> 16;
+        return c;
+    }
+    const uint32_t len = ZG_TOK_LEN(tok), dist = ZG_TOK_DIST(tok);
+    const uint32_t li = length_code_index(len);  // length_writer
+    const uint32_t lt = ll[257u + li];
+    uint64_t bits = lt & 0xFFFFu;
+    uint32_t n = lt >> 16;
+    const uint32_t leb = length_extra_bits(li);
+    bits |= (uint64_t)(len - length_base(li)) << n;
+    n += leb;
+    const uint32_t dc = dist_code(dist);  // distance_writer
+    const uint32_t dtab = dt[dc];
+    bits |= (uint64_t)(dtab & 0xFFFFu) << n;
+    n += dtab >> 16;
+    const uint32_t deb = dist_extra_bits(dc);
+    bits |= (uint64_t)(dist - dist_base(dc)) << n;
+    n += deb;
+    c.bits = bits;
+    c.n = n;
+    return c;
+}
+constexpr uint32_t kTokEob = 0x100u;  // virtual unit: end-of-block symbol 256 (literal path of code_unit)
+
+__global__ __launch_bounds__(kEncThreads) void k_tile_bits(uint32_t max_tiles, const uint32_t *__restrict__ tokens,
+                                                            uint64_t first, uint64_t chunk_bytes, uint32_t c0,
+                                                            uint64_t tok_base, const uint32_t *__restrict__ ntok,
+                                                            const uint32_t *__restrict__ tab,
+                                                            uint32_t *__restrict__ tile_bits) {
+    __shared__ uint32_t s_ll[kHuffMaxSyms];
+    __shared__ uint32_t s_d[32];
+    __shared__ uint32_t s_red[kEncThreads / 64];
+    const uint32_t ci = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t nunits = ntok[ci] + 1u;  // + end of block
+    if ((uint64_t)tile * kEncTile >= nunits) return;
+    for (uint32_t i = tid; i < kHuffMaxSyms; i += kEncThreads) s_ll[i] = tab[(uint64_t)ci * kTabStride + i];
+    if (tid < 32) s_d[tid] = tab[(uint64_t)ci * kTabStride + kDOff + tid];
+    __syncthreads();
+    const uint32_t *tok = tokens + (first + (uint64_t)(c0 + ci) * chunk_bytes - tok_base);
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < kEncTile / kEncThreads; k++) {
+        const uint32_t u = tile * kEncTile + k * kEncThreads + tid;
+        if (u < nunits) sum += code_unit(u + 1 == nunits ? kTokEob : tok[u], s_ll, s_d).n;
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if ((tid & 63) == 0) s_red[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t t = 0;
+        for (uint32_t i = 0; i < kEncThreads / 64; i++) t += s_red[i];
+        tile_bits[(uint64_t)ci * max_tiles + tile] = t;
+    }
+}
+
+// exclusive scan of each chunk's tile sums (in place), one workgroup per chunk
+__global__ __launch_bounds__(256) void k_tile_scan(uint32_t max_tiles, const uint32_t *__restrict__ ntok,
+                                                    uint32_t *__restrict__ tile_bits) {
+    __shared__ uint32_t s_part[256];
+    const uint32_t ci = blockIdx.x, tid = threadIdx.x;
+    const uint32_t nt = (ntok[ci] + 1u + kEncTile - 1) / kEncTile;
+    uint32_t *tb = tile_bits + (uint64_t)ci * max_tiles;
+    const uint32_t per = (nt + 255) / 256;
+    const uint32_t lo = tid * per, hi = (lo + per < nt) ? lo + per : nt;
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += tb[i];
+    s_part[tid] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        const uint32_t v = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - s;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = tb[i];
+        tb[i] = run;
+        run += v;
+    }
+}
+
+// absolute bit offset of every block: carry[0] is the offset of the first
+// block of this batch on entry and of the next batch on exit
+__global__ __launch_bounds__(256) void k_block_offsets(uint32_t n_chunks, const uint64_t *__restrict__ block_bits,
+                                                        uint64_t *__restrict__ bit_off, uint64_t *carry) {
+    __shared__ uint64_t s_part[256];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_chunks + 255) / 256;
+    const uint32_t lo = tid * per, hi = (lo + per < n_chunks) ? lo + per : n_chunks;
+    uint64_t s = 0;
+    for (uint32_t i = lo; i < hi && lo < n_chunks; i++) s += block_bits[i];
+    s_part[tid] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        const uint64_t v = tid >= off ? s_part[tid - off] : 0ull;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    const uint64_t base = carry[0];
+    uint64_t run = base + s_part[tid] - s;
+    for (uint32_t i = lo; i < hi && lo < n_chunks; i++) {
+        bit_off[i] = run;
+        run += block_bits[i];
+    }
+    __syncthreads();
+    if (tid == 255) carry[0] = base + s_part[255];
+}
+
+hipError_t launch_tile_bits(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *tokens, const ChunkGrid &g,
+                            uint32_t c0, uint64_t tok_base, const uint32_t *ntok, const uint32_t *tab,
+                            uint32_t *tile_bits, hipStream_t s) {
+    if (!n_chunks) return hipSuccess;
+    hipLaunchKernelGGL(k_tile_bits, dim3(max_tiles, n_chunks), dim3(kEncThreads), 0, s, max_tiles, tokens, g.first,
+                       g.chunk_bytes, c0, tok_base, ntok, tab, tile_bits);
+    return hipGetLastError();
+}
+hipError_t launch_offsets(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *ntok, uint32_t *tile_bits,
+                          const uint64_t *block_bits, uint64_t *bit_off, uint64_t *carry, hipStream_t s) {
+    if (!n_chunks) return hipSuccess;
+    hipLaunchKernelGGL(k_tile_scan, dim3(n_chunks), dim3(256), 0, s, max_tiles, ntok, tile_bits);
+    hipLaunchKernelGGL(k_block_offsets, dim3(1), dim3(256), 0, s, n_chunks, block_bits, bit_off, carry);
+    return hipGetLastError();
+}
+
+// k_encode: one workgroup per tile of units.  Units are packed into an LDS
+// image of the tile's bit range with LDS atomic OR, then the image is written
+// out: interior words with plain stores, the two boundary words (shared with
+// the neighbouring tile, block header or block) with global atomic OR.  The
+// output buffer must be zero before the first launch.
+constexpr uint32_t kEncWords = (kEncTile * 48u + 31u) / 32u + 3u;
+
+__global__ __launch_bounds__(kEncThreads) void k_encode(uint32_t max_tiles, const uint32_t *__restrict__ tokens,
+                                                         uint64_t first, uint64_t chunk_bytes, uint32_t c0,
+                                                         uint64_t tok_base, const uint32_t *__restrict__ ntok,
+                                                         const uint32_t *__restrict__ tab,
+                                                         const uint32_t *__restrict__ hdr,
+                                                         const uint32_t *__restrict__ hdr_bits,
+                                                         const uint32_t *__restrict__ tile_off,
+                                                         const uint64_t *__restrict__ bit_off, uint32_t *out,
+                                                         uint64_t out_cap_bits, uint32_t *status) {
+    __shared__ uint32_t s_ll[kHuffMaxSyms];
+    __shared__ uint32_t s_d[32];
+    __shared__ uint32_t s_img[kEncWords];
+    __shared__ uint32_t s_scan[kEncThreads];
+
+    const uint32_t ci = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t nunits = ntok[ci] + 1u;
+    if ((uint64_t)tile * kEncTile >= nunits) return;
+    const uint64_t blk_bit = bit_off[ci];
+    const uint32_t hb = hdr_bits[ci];
+    const uint64_t tile_bit = blk_bit + hb + tile_off[(uint64_t)ci * max_tiles + tile];
+
+    for (uint32_t i = tid; i < kHuffMaxSyms; i += kEncThreads) s_ll[i] = tab[(uint64_t)ci * kTabStride + i];
+    if (tid < 32) s_d[tid] = tab[(uint64_t)ci * kTabStride + kDOff + tid];
+    for (uint32_t i = tid; i < kEncWords; i += kEncThreads) s_img[i] = 0;
+    __syncthreads();
+
+    // the block header travels with tile 0
+    if (tile == 0) {
+        const uint32_t nw = (hb + 31u) >> 5;
+        const uint32_t sh = (uint32_t)(blk_bit & 31u);
+        const uint64_t w0 = blk_bit >> 5;
+        if (blk_bit + hb > out_cap_bits) {
+            if (tid == 0) atomicOr(status, 1u);
+        } else {
+            for (uint32_t i = tid; i < nw; i += kEncThreads) {
+                const uint32_t v = hdr[(uint64_t)ci * kHdrWords + i];
+                if (v) {
+                    atomicOr(&out[w0 + i], v << sh);
+                    if (sh) atomicOr(&out[w0 + i + 1], v >> (32u - sh));
+                }
+            }
+        }
+    }
+
+    constexpr uint32_t kPer = kEncTile / kEncThreads;
+    const uint32_t *tok = tokens + (first + (uint64_t)(c0 + ci) * chunk_bytes - tok_base);
+    Coded cu[kPer];
+    uint32_t sum = 0;
+    const uint32_t u0 = tile * kEncTile + tid * kPer;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) {
+        const uint32_t u = u0 + k;
+        if (u < nunits) {
+            cu[k] = code_unit(u + 1 == nunits ? kTokEob : tok[u], s_ll, s_d);
+        } else {
+            cu[k].bits = 0;
+            cu[k].n = 0;
+        }
+        sum += cu[k].n;
+    }
+    s_scan[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < kEncThreads; off <<= 1) {
+        const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t total = s_scan[kEncThreads - 1];
+    const uint32_t img_sh = (uint32_t)(tile_bit & 31u);  // bit position of the tile start inside image word 0
+    uint32_t pos = img_sh + s_scan[tid] - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) {
+        const uint32_t n = cu[k].n;
+        if (n) {
+            const uint32_t w = pos >> 5, sh = pos & 31u;
+            const uint64_t lo = cu[k].bits << sh;
+            atomicOr(&s_img[w], (uint32_t)lo);
+            if (sh + n > 32) atomicOr(&s_img[w + 1], (uint32_t)(lo >> 32));
+            if (sh + n > 64) atomicOr(&s_img[w + 2], (uint32_t)(cu[k].bits >> (64u - sh)));
+            pos += n;
+        }
+    }
+    __syncthreads();
+    if (total == 0) return;
+    if (tile_bit + total > out_cap_bits) {
+        if (tid == 0) atomicOr(status, 1u);
+        return;
+    }
+    const uint32_t nw = (img_sh + total + 31u) >> 5;
+    const uint64_t w0 = tile_bit >> 5;
+    for (uint32_t i = tid; i < nw; i += kEncThreads) {
+        const uint32_t v = s_img[i];
+        if (i == 0 || i + 1 == nw) {
+            if (v) atomicOr(&out[w0 + i], v);
+        } else {
+            out[w0 + i] = v;
+        }
+    }
+}
+
+hipError_t launch_encode(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *tokens, const ChunkGrid &g,
+                         uint32_t c0, uint64_t tok_base, const uint32_t *ntok, const uint32_t *tab,
+                         const uint32_t *hdr, const uint32_t *hdr_bits, const uint32_t *tile_off,
+                         const uint64_t *bit_off, uint32_t *out, uint64_t out_cap_bits, uint32_t *status,
+                         hipStream_t s) {
+    if (!n_chunks) return hipSuccess;
+    hipLaunchKernelGGL(k_encode, dim3(max_tiles, n_chunks), dim3(kEncThreads), 0, s, max_tiles, tokens, g.first,
+                       g.chunk_bytes, c0, tok_base, ntok, tab, hdr, hdr_bits, tile_off, bit_off, out, out_cap_bits,
+                       status);
+    return hipGetLastError();
+}
+
+}  // namespace zg

@@ -1,0 +1,83 @@
+// Internal declarations shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/zlib_amd.h"
+
+namespace zg {
+
+constexpr uint32_t kMaxWindow = 32768;  // MAX_WINDOW_SIZE, src/lz77.rs:20
+constexpr uint32_t kMaxMatch = 258;     // largest max_match_length the device path accepts
+constexpr uint32_t kNumLL = 286;        // literal/length alphabet, src/huffman.rs:785-789
+constexpr uint32_t kNumD = 30;          // distance alphabet, src/huffman.rs:808-810
+constexpr uint32_t kDOff = 288;         // offset of the distance part inside per-chunk tables
+constexpr uint32_t kTabStride = 320;    // u32 words per chunk in freq / code tables
+constexpr uint32_t kHdrWords = 160;     // u32 words reserved per chunk for the block header bits
+constexpr uint32_t kStoredBlock = 16384;  // SIXTEEN_KB, src/compress.rs:14
+
+// index kernel geometry
+constexpr uint32_t kIdxHashBits = 12;
+constexpr uint32_t kIdxBuckets = 1u << kIdxHashBits;
+constexpr uint32_t kIdxSegment = 256 * 1024;  // positions owned by one index workgroup
+
+// match kernel geometry
+constexpr uint32_t kMatchTile = 16384;  // positions resolved by one match workgroup
+constexpr uint32_t kMatchThreads = 1024;
+
+// parse kernel geometry
+constexpr uint32_t kParseTile = 8192;
+constexpr uint32_t kParseThreads = 256;
+
+// encode kernel geometry
+constexpr uint32_t kEncTile = 2048;  // tokens per encode workgroup
+constexpr uint32_t kEncThreads = 256;
+
+struct MatchParams {
+    uint32_t window;   // LZ77Compressor::window_size
+    uint32_t min_len;  // LZ77Compressor::min_match_length
+    uint32_t max_len;  // LZ77Compressor::max_match_length
+};
+
+// A view of device-resident input: `data` points at view position 0.
+// Positions are view-relative.  Chunk c covers
+// [first + c*chunk_bytes, min(end, first + (c+1)*chunk_bytes)).
+struct ChunkGrid {
+    const uint8_t *data;
+    uint64_t first;        // view position of the first owned byte (= halo length)
+    uint64_t end;          // view position one past the last owned byte
+    uint64_t chunk_bytes;
+    uint32_t n_chunks;     // >= 1 (an empty input has one empty chunk)
+};
+
+// launchers (each enqueues on `s` and returns the HIP status of the launch)
+hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
+                        uint32_t window, uint16_t *far, uint16_t *next, uint64_t base, hipStream_t s);
+hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *far,
+                        const uint16_t *next, uint64_t base, uint32_t *match, hipStream_t s);
+hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint32_t *match, uint64_t base,
+                        uint32_t *tokens, uint64_t tok_base, uint32_t *ntok, uint32_t *freq, hipStream_t s);
+hipError_t launch_histogram(const uint32_t *tokens, uint64_t n, uint32_t *freq, hipStream_t s);
+hipError_t launch_huffman(uint32_t n_chunks, int strategy, const uint32_t *freq, int64_t final_chunk, uint32_t *tab,
+                          uint32_t *hdr, uint32_t *hdr_bits, uint64_t *block_bits, hipStream_t s);
+hipError_t launch_tile_bits(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *tokens, const ChunkGrid &g,
+                            uint32_t c0, uint64_t tok_base, const uint32_t *ntok, const uint32_t *tab,
+                            uint32_t *tile_bits, hipStream_t s);
+hipError_t launch_offsets(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *ntok, uint32_t *tile_bits,
+                          const uint64_t *block_bits, uint64_t *bit_off, uint64_t *carry, hipStream_t s);
+hipError_t launch_encode(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *tokens, const ChunkGrid &g,
+                         uint32_t c0, uint64_t tok_base, const uint32_t *ntok, const uint32_t *tab,
+                         const uint32_t *hdr, const uint32_t *hdr_bits, const uint32_t *tile_off,
+                         const uint64_t *bit_off, uint32_t *out, uint64_t out_cap_bits, uint32_t *status,
+                         hipStream_t s);
+hipError_t launch_adler(const uint8_t *data, uint64_t n, uint64_t seg_bytes, uint32_t n_seg, uint32_t *partial,
+                        hipStream_t s);
+hipError_t launch_adler_fold(const uint32_t *partial, uint64_t n, uint64_t seg_bytes, uint32_t n_seg,
+                             uint32_t *state /* [a, b] running */, hipStream_t s);
+hipError_t launch_stored(const uint8_t *data, uint64_t n, uint8_t *out, hipStream_t s);
+hipError_t launch_trailer(uint8_t *out, const uint64_t *total_bits, const uint32_t *adler_state,
+                          uint32_t adler_override, int use_override, int write_header, int write_adler,
+                          uint64_t *out_bytes, hipStream_t s);
+
+}  // namespace zg

@@ -1,0 +1,262 @@
+// LZ77 match finding for gfx950: a forward-chain 3-gram index (k_index) and an
+// exhaustive, position-parallel longest-match search over LDS-staged windows
+// (k_match).  Together they reproduce, for EVERY position of a chunk, the
+// result of the candidate loop of LZ77Compressor::compress
+// (reference src/lz77.rs:156-190):
+//
+//   candidates s run upward from max(0, pos - window) while s + min_len < pos;
+//   M(s) = common prefix of data[s..] and data[pos..], capped at
+//          min(chunk_end - pos, max_len - 1);
+//   a candidate with M >= min_len and s + M + 1 >= pos ends the whole search
+//          (the reference's loop guard fails while the match is still growing);
+//   otherwise it is recorded iff M >= min_len and M > best (strict: ties keep
+//          the farthest candidate).
+//
+// Only positions sharing the first three bytes can reach M >= min_len (>= 3),
+// so walking the per-hash forward chain from the farthest in-window member
+// visits every relevant candidate in the reference's order.
+#include "zg_internal.h"
+
+namespace zg {
+
+// ---------------------------------------------------------------------------
+// k_index: one wave per segment walks positions in batches of 64, keeping per
+// hash bucket the newest member (head) and the farthest in-window member
+// (tail), plus a 64 Ki-entry ring of forward links.  Outputs, per position p:
+//   far[p]  = p - (smallest bucket member >= p - window), 0 if none
+//   next[s] = distance from s to the next bucket member, 0 if none within window
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hash3(uint32_t tri) { return (tri * 0x9E3779B1u) >> (32 - kIdxHashBits); }
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(64) void k_index(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
+                                               uint64_t r1, uint64_t far_lo, uint32_t window,
+                                               uint16_t *__restrict__ far, uint16_t *__restrict__ next,
+                                               uint64_t base) {
+    __shared__ uint32_t s_head[kIdxBuckets];    // newest member + 1 (segment-relative), 0 = empty
+    __shared__ uint16_t s_tail[kIdxBuckets];    // low 16 bits of the farthest in-window member
+    __shared__ uint16_t s_ring[65536];          // forward link of position (q & 0xFFFF)
+
+    const uint32_t lane = threadIdx.x;
+    const uint64_t a = r0 + (uint64_t)blockIdx.x * kIdxSegment;  // first owned position
+    const uint64_t b = (a + kIdxSegment < r1) ? a + kIdxSegment : r1;
+    const uint64_t a0 = a > window ? a - window : 0;  // warm-up start
+    if (a >= r1) return;
+
+    for (uint32_t i = lane; i < kIdxBuckets; i += 64) s_head[i] = 0;
+    for (uint32_t i = lane; i < 65536 / 2; i += 64) reinterpret_cast<uint32_t *>(s_ring)[i] = 0;
+    __syncthreads();
+
+    const uint32_t q_end = (uint32_t)(b - a0);
+    const uint32_t q_main = (uint32_t)(a - a0);
+    for (uint32_t qb = 0; qb < q_end; qb += 64) {
+        const uint32_t q = qb + lane;
+        const uint64_t p = a0 + q;
+        const bool inseg = q < q_end;
+        const bool valid = inseg && (p + 3 <= n_view);
+        uint32_t h = 0;
+        if (valid) {
+            uint32_t tri = (uint32_t)data[p] | ((uint32_t)data[p + 1] << 8) | ((uint32_t)data[p + 2] << 16);
+            h = hash3(tri);
+        }
+        // lanes of this batch that share my bucket
+        uint64_t mygrp = 0;
+        uint64_t todo = __ballot(valid);
+        while (todo) {
+            const int leader = __ffsll((unsigned long long)todo) - 1;
+            const uint32_t hl = __shfl(h, leader);
+            const bool same = valid && (h == hl);
+            const uint64_t grp = __ballot(same);
+            if (same) mygrp = grp;
+            todo &= ~grp;
+        }
+        uint32_t pp = kNone;  // previous bucket member (segment-relative)
+        uint32_t f = kNone;   // farthest in-window bucket member
+        bool is_last = false;
+        if (valid) {
+            const uint64_t below = mygrp & ((1ull << lane) - 1ull);
+            const int prevlane = below ? 63 - __clzll((long long)below) : -1;
+            const int firstlane = __ffsll((unsigned long long)mygrp) - 1;
+            is_last = (mygrp >> lane) == 1ull;
+            const uint32_t hq1 = s_head[h];
+            const uint32_t hq = hq1 - 1u;
+            const bool has_old = hq1 != 0u && (q - hq) <= window;
+            if (prevlane >= 0)
+                pp = qb + (uint32_t)prevlane;
+            else if (has_old)
+                pp = hq;
+            if (has_old) {
+                uint32_t t = hq - ((hq - (uint32_t)s_tail[h]) & 0xFFFFu);
+                const uint32_t lo = q > window ? q - window : 0u;
+                // every link on the way from tail to head was written in an earlier batch
+                for (int guard = 0; t < lo && guard < 65536; ++guard) {
+                    const uint32_t dl = s_ring[t & 0xFFFFu];
+                    if (dl == 0) break;
+                    t += dl;
+                }
+                f = t;
+            } else if (prevlane >= 0) {
+                f = qb + (uint32_t)firstlane;
+            }
+        }
+        // all reads of this batch are done (one wave, program order); now publish
+        if (valid) s_ring[q & 0xFFFFu] = 0;
+        if (valid && pp != kNone) s_ring[pp & 0xFFFFu] = (uint16_t)(q - pp);
+        if (valid && is_last) {
+            s_head[h] = q + 1u;
+            s_tail[h] = (uint16_t)((f != kNone ? f : q) & 0xFFFFu);
+        }
+        if (inseg && q >= q_main) {
+            if (valid && pp != kNone && a0 + pp >= base) next[(a0 + pp) - base] = (uint16_t)(q - pp);
+            if (p >= far_lo) far[p - base] = (valid && f != kNone) ? (uint16_t)(q - f) : (uint16_t)0;
+        }
+    }
+}
+
+hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
+                        uint32_t window, uint16_t *far, uint16_t *next, uint64_t base, hipStream_t s) {
+    if (r1 <= r0) return hipSuccess;
+    const uint64_t nseg = (r1 - r0 + kIdxSegment - 1) / kIdxSegment;
+    hipLaunchKernelGGL(k_index, dim3((uint32_t)nseg), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, far,
+                       next, base);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// k_match: one workgroup per tile of kMatchTile positions.  The tile's bytes
+// plus the preceding window and the forward links of that range are staged in
+// LDS; each thread then resolves positions tid, tid + 1024, ... of the tile.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kDataLds = kMaxWindow + kMatchTile + 16 + 272;  // 16: alignment slack, 272: look-ahead + pad
+constexpr uint32_t kNextLds = kMaxWindow + kMatchTile + 16;
+
+// four bytes at an arbitrary LDS byte offset, from two aligned dwords
+__device__ __forceinline__ uint32_t lds_ld4(const uint8_t *lds, uint32_t off) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(lds + (off & ~3u));
+    const uint32_t lo = w[0], hi = w[1];
+    return __builtin_amdgcn_alignbyte(hi, lo, off & 3u);
+}
+
+// common prefix of the strings at LDS offsets so and po, at most cap bytes
+__device__ __forceinline__ uint32_t lds_lcp(const uint8_t *lds, uint32_t so, uint32_t po, uint32_t cap) {
+    uint32_t m = 0;
+    while (m < cap) {
+        const uint32_t x = lds_ld4(lds, so + m) ^ lds_ld4(lds, po + m);
+        if (x) {
+            m += (uint32_t)__builtin_ctz(x) >> 3;
+            break;
+        }
+        m += 4;
+    }
+    return m < cap ? m : cap;
+}
+
+__global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restrict__ data, uint64_t first,
+                                                          uint64_t end, uint64_t chunk_bytes, uint32_t c0,
+                                                          uint32_t tiles_per_chunk, MatchParams mp,
+                                                          const uint16_t *__restrict__ far,
+                                                          const uint16_t *__restrict__ next, uint64_t base,
+                                                          uint32_t *__restrict__ match) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_data[kDataLds];
+    __shared__ __attribute__((aligned(16))) uint16_t s_next[kNextLds];
+
+    const uint32_t chunk = c0 + blockIdx.x / tiles_per_chunk;
+    const uint32_t tile = blockIdx.x % tiles_per_chunk;
+    const uint64_t cs = first + (uint64_t)chunk * chunk_bytes;
+    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+    const uint64_t t0 = cs + (uint64_t)tile * kMatchTile;
+    if (t0 >= ce) return;
+    const uint64_t t1 = (t0 + kMatchTile < ce) ? t0 + kMatchTile : ce;
+    const uint64_t w0 = (t0 > mp.window ? t0 - mp.window : 0) & ~(uint64_t)15;  // LDS origin, 16-byte aligned
+    const uint64_t w1 = (t1 + mp.max_len < ce) ? t1 + mp.max_len : ce;          // bytes needed: [w0, w1)
+    const uint32_t nbytes = (uint32_t)(w1 - w0);
+    const uint32_t nlinks = (uint32_t)(t1 - w0);
+    const uint32_t tid = threadIdx.x;
+
+    // stage bytes: 16-byte vectors when the source is aligned, bytes otherwise
+    if (((reinterpret_cast<uintptr_t>(data) + w0) & 15) == 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(data + w0);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_data);
+        const uint32_t nv = nbytes >> 4;
+        for (uint32_t i = tid; i < nv; i += kMatchThreads) dst[i] = src[i];
+        for (uint32_t i = (nv << 4) + tid; i < nbytes; i += kMatchThreads) s_data[i] = data[w0 + i];
+    } else {
+        for (uint32_t i = tid; i < nbytes; i += kMatchThreads) s_data[i] = data[w0 + i];
+    }
+    for (uint32_t i = nbytes + tid; i < nbytes + 16 && i < kDataLds; i += kMatchThreads) s_data[i] = 0;
+    {
+        const uint16_t *src = next + (w0 - base);
+        if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+            uint4 *d4 = reinterpret_cast<uint4 *>(s_next);
+            const uint32_t nv = nlinks >> 3;
+            for (uint32_t i = tid; i < nv; i += kMatchThreads) d4[i] = s4[i];
+            for (uint32_t i = (nv << 3) + tid; i < nlinks; i += kMatchThreads) s_next[i] = src[i];
+        } else {
+            for (uint32_t i = tid; i < nlinks; i += kMatchThreads) s_next[i] = src[i];
+        }
+    }
+    __syncthreads();
+
+    const uint32_t min_len = mp.min_len, max_len = mp.max_len;
+    for (uint64_t p = t0 + tid; p < t1; p += kMatchThreads) {
+        uint32_t best = 0, bestd = 0;
+        const uint64_t remain = ce - p;
+        uint32_t cap = remain < (uint64_t)(max_len - 1) ? (uint32_t)remain : max_len - 1;
+        const uint32_t fd = far[p - base];
+        // the reference searches only while pos < len - min_len, and records nothing below min_len
+        if (fd != 0 && remain > min_len && cap >= min_len) {
+            const uint32_t po = (uint32_t)(p - w0);
+            uint32_t so = po - fd;
+            const uint32_t p0 = lds_ld4(s_data, po);
+            for (;;) {
+                const uint32_t d = po - so;
+                if (d <= min_len) break;  // loop guard: s + min_len < pos
+                const uint32_t x0 = lds_ld4(s_data, so) ^ p0;
+                if ((x0 & 0x00FFFFFFu) == 0) {  // first three bytes agree
+                    if (d > max_len) {
+                        // cannot end the search; only a strictly longer match matters
+                        bool maybe = true;
+                        if (best >= 3) maybe = lds_ld4(s_data, so + best - 3) == lds_ld4(s_data, po + best - 3);
+                        if (maybe) {
+                            const uint32_t m = lds_lcp(s_data, so, po, cap);
+                            if (m >= min_len && m > best) {
+                                best = m;
+                                bestd = d;
+                                if (best == cap) break;
+                            }
+                        }
+                    } else {
+                        const uint32_t m = lds_lcp(s_data, so, po, cap);
+                        if (m >= min_len) {
+                            if (m + 1 >= d) break;  // the growing match reached pos: search over
+                            if (m > best) {
+                                best = m;
+                                bestd = d;
+                                if (best == cap) break;
+                            }
+                        }
+                    }
+                }
+                const uint32_t nx = s_next[so];
+                if (nx == 0) break;
+                so += nx;
+                if (so >= po) break;
+            }
+        }
+        match[p - base] = best ? ((best << 16) | bestd) : 0u;
+    }
+}
+
+hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *far,
+                        const uint16_t *next, uint64_t base, uint32_t *match, hipStream_t s) {
+    if (c1 <= c0) return hipSuccess;
+    const uint32_t tpc = (uint32_t)((g.chunk_bytes + kMatchTile - 1) / kMatchTile);
+    const uint64_t nblocks = (uint64_t)(c1 - c0) * tpc;
+    hipLaunchKernelGGL(k_match, dim3((uint32_t)nblocks), dim3(kMatchThreads), 0, s, g.data, g.first, g.end,
+                       g.chunk_bytes, c0, tpc, mp, far, next, base, match);
+    return hipGetLastError();
+}
+
+}  // namespace zg
