@@ -69,6 +69,8 @@ struct zg_ctx {
     int shard_strategy = 0;
     uint32_t shard_max_tiles = 0;
     uint64_t shard_total_bits = 0;
+    // set once the exchange-based index kernel has reported an out-of-order exchange: use k_index from then on
+    bool index_safe = false;
     // profiling
     bool prof = false;
     struct Ev {
@@ -204,7 +206,8 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
     if (span) {
         LAUNCH(K_MISC, hipMemsetAsync(c->next.p, 0, span * 2, c->stream));
         LAUNCH(K_INDEX, launch_index(g.data, g.end, ib0, be, bs, mp.window, c->far.as<uint16_t>(),
-                                     c->next.as<uint16_t>(), ib0, c->stream));
+                                     c->next.as<uint16_t>(), ib0, &c->scalars.as<Scalars>()->status, c->index_safe,
+                                     c->stream));
         LAUNCH(K_MATCH, launch_match(g, c0, c1, mp, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
                                      c->match.as<uint32_t>(), c->stream));
     }
@@ -262,8 +265,10 @@ size_t stored_size(size_t n) {
     return 2 + n + 5 * nb + 4;
 }
 
-int compress_device_locked(zg_ctx *c, const uint8_t *d_in, size_t n, int strategy, const zg_opts *opts,
-                           uint8_t *d_out, size_t out_cap, size_t *out_n) {
+constexpr int kRetrySafe = 1;  // internal: the index kernel asked for the conservative variant
+
+int compress_device_once(zg_ctx *c, const uint8_t *d_in, size_t n, int strategy, const zg_opts *opts,
+                         uint8_t *d_out, size_t out_cap, size_t *out_n) {
     Plan plan;
     int rc = make_plan(opts, &plan);
     if (rc) return rc;
@@ -319,9 +324,20 @@ int compress_device_locked(zg_ctx *c, const uint8_t *d_in, size_t n, int strateg
     HIPCHK(hipMemcpyAsync(&h, c->scalars.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->prof) prof_collect(c);
+    if (h.status & 2u) return kRetrySafe;
     if (h.status & 1u) return ZG_ERR_CAPACITY;
     *out_n = (size_t)h.out_bytes;
     return ZG_OK;
+}
+
+int compress_device_locked(zg_ctx *c, const uint8_t *d_in, size_t n, int strategy, const zg_opts *opts,
+                           uint8_t *d_out, size_t out_cap, size_t *out_n) {
+    int rc = compress_device_once(c, d_in, n, strategy, opts, d_out, out_cap, out_n);
+    if (rc == kRetrySafe) {
+        c->index_safe = true;
+        rc = compress_device_once(c, d_in, n, strategy, opts, d_out, out_cap, out_n);
+    }
+    return rc;
 }
 
 zg_ctx *resolve(zg_ctx *ctx, int *rc) {
@@ -502,11 +518,19 @@ int zg_lz77(zg_ctx *ctx, const uint8_t *in, size_t n, size_t start, uint32_t win
     g.n_chunks = 1;
     rc = ensure_chunk_meta(c, 1, 1);
     if (rc) return rc;
-    rc = run_front(c, g, 0, 1, MatchParams{window, min_len, max_len}, ZG_DYNAMIC, -1, false);
-    if (rc) return rc;
     uint32_t nt = 0;
-    HIPCHK(hipMemcpyAsync(&nt, c->ntok.p, sizeof nt, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        rc = init_scalars(c, 0);
+        if (rc) return rc;
+        rc = run_front(c, g, 0, 1, MatchParams{window, min_len, max_len}, ZG_DYNAMIC, -1, false);
+        if (rc) return rc;
+        Scalars hs;
+        HIPCHK(hipMemcpyAsync(&nt, c->ntok.p, sizeof nt, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&hs, c->scalars.p, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!(hs.status & 2u)) break;
+        c->index_safe = true;
+    }
     uint32_t *h = static_cast<uint32_t *>(malloc((nt ? nt : 1) * sizeof(uint32_t)));
     if (!h) return ZG_ERR_NOMEM;
     if (nt) HIPCHK(hipMemcpy(h, c->tokens.p, (size_t)nt * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -596,6 +620,13 @@ int zg_shard_begin(zg_ctx *ctx, const void *d_in, size_t halo, size_t n, int str
     Scalars h;
     HIPCHK(hipMemcpyAsync(&h, c->scalars.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if ((h.status & 2u) && !c->index_safe) {  // redo with the conservative index kernel
+        c->index_safe = true;
+        c->mu.unlock();
+        const int again = zg_shard_begin(c, d_in, halo, n, strategy, opts, last_rank, info);
+        c->mu.lock();
+        return again;
+    }
     info->total_bits = h.carry;
     info->adler = (h.adler[1] << 16) | h.adler[0];
     info->n_chunks = g.n_chunks;

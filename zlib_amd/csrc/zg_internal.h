@@ -53,7 +53,8 @@ struct ChunkGrid {
 
 // launchers (each enqueues on `s` and returns the HIP status of the launch)
 hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
-                        uint32_t window, uint16_t *far, uint16_t *next, uint64_t base, hipStream_t s);
+                        uint32_t window, uint16_t *far, uint16_t *next, uint64_t base, uint32_t *status, bool safe,
+                        hipStream_t s);
 hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *far,
                         const uint16_t *next, uint64_t base, uint32_t *match, hipStream_t s);
 hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint32_t *match, uint64_t base,

@@ -114,12 +114,113 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t *__restrict__ data, 
     }
 }
 
+// k_index_x: the same index, with the per-batch grouping done by the LDS itself.  One ds_wrxchg on the bucket
+// head hands every lane the bucket member inserted just before it, including lanes of the same batch, PROVIDED
+// the LDS serialises same-address lanes of one instruction in ascending lane order.  gfx950 does (probed over
+// 10^9 colliding exchanges, tools/probe/probe_exch.hip); the kernel still checks every returned value (a member
+// handed out of order is >= the lane's own position) and raises bit 1 of *status, upon which the host redoes
+// the batch with k_index.
+__global__ __launch_bounds__(64) void k_index_x(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
+                                                 uint64_t r1, uint64_t far_lo, uint32_t window,
+                                                 uint16_t *__restrict__ far, uint16_t *__restrict__ next,
+                                                 uint64_t base, uint32_t *status) {
+    __shared__ uint32_t s_head[kIdxBuckets];
+    __shared__ uint16_t s_tail[kIdxBuckets];
+    __shared__ uint16_t s_ring[65536];
+
+    const uint32_t lane = threadIdx.x;
+    const uint64_t a = r0 + (uint64_t)blockIdx.x * kIdxSegment;
+    const uint64_t b = (a + kIdxSegment < r1) ? a + kIdxSegment : r1;
+    const uint64_t a0 = a > window ? a - window : 0;
+    if (a >= r1) return;
+
+    for (uint32_t i = lane; i < kIdxBuckets; i += 64) s_head[i] = 0;
+    for (uint32_t i = lane; i < 65536 / 2; i += 64) reinterpret_cast<uint32_t *>(s_ring)[i] = 0;
+    __syncthreads();
+
+    const uint32_t q_end = (uint32_t)(b - a0);
+    const uint32_t q_main = (uint32_t)(a - a0);
+    bool violated = false;
+
+    auto load_tri = [&](uint32_t q) -> uint32_t {  // three bytes at segment position q, ~0 if none
+        const uint64_t p = a0 + q;
+        if (q < q_end && p + 3 <= n_view)
+            return (uint32_t)data[p] | ((uint32_t)data[p + 1] << 8) | ((uint32_t)data[p + 2] << 16);
+        return 0xFFFFFFFFu;
+    };
+    uint32_t tri_next = load_tri(lane);
+    for (uint32_t qb = 0; qb < q_end; qb += 64) {
+        const uint32_t q = qb + lane;
+        const uint64_t p = a0 + q;
+        const uint32_t tri = tri_next;
+        tri_next = load_tri(q + 64);  // in flight while this batch is processed
+        const bool inseg = q < q_end;
+        const bool valid = tri != 0xFFFFFFFFu;
+        const uint32_t h = valid ? hash3(tri) : 0u;
+
+        uint32_t t16 = 0, old1 = 0;
+        if (valid) {
+            t16 = s_tail[h];                       // tail as the previous batches left it
+            old1 = atomicExch(&s_head[h], q + 1u);  // member inserted just before me, +1
+            violated |= (old1 != 0u && old1 - 1u >= q);
+        }
+        const bool in_batch = valid && old1 != 0u && (old1 - 1u) >= qb && (old1 - 1u) < q;
+        // first lane of my bucket within this batch (pointer jumping over the in-batch links)
+        uint32_t root = in_batch ? (old1 - 1u - qb) : lane;
+        if (__any(in_batch)) {
+            for (int k = 0; k < 6; k++) {
+                const uint32_t rr = __shfl(root, (int)root);
+                if (!__any(rr != root)) break;
+                root = rr;
+            }
+        }
+        const uint32_t head1 = __shfl(old1, (int)root);  // bucket head + 1 before this batch
+
+        uint32_t pp = kNone, f = kNone;
+        bool is_last = false;
+        if (valid) {
+            const uint32_t hq = head1 - 1u;
+            const bool has_old = head1 != 0u && hq < qb && (q - hq) <= window;
+            if (in_batch)
+                pp = old1 - 1u;
+            else if (has_old)
+                pp = hq;
+            if (has_old) {
+                uint32_t t = hq - ((hq - t16) & 0xFFFFu);
+                const uint32_t lo = q > window ? q - window : 0u;
+                for (int guard = 0; t < lo && guard < 65536; ++guard) {
+                    const uint32_t dl = s_ring[t & 0xFFFFu];
+                    if (dl == 0) break;
+                    t += dl;
+                }
+                f = t;
+            } else if (root != lane) {
+                f = qb + root;
+            }
+            is_last = s_head[h] == q + 1u;
+        }
+        if (valid) s_ring[q & 0xFFFFu] = 0;
+        if (valid && pp != kNone) s_ring[pp & 0xFFFFu] = (uint16_t)(q - pp);
+        if (valid && is_last) s_tail[h] = (uint16_t)((f != kNone ? f : q) & 0xFFFFu);
+        if (inseg && q >= q_main) {
+            if (valid && pp != kNone && a0 + pp >= base) next[(a0 + pp) - base] = (uint16_t)(q - pp);
+            if (p >= far_lo) far[p - base] = (valid && f != kNone) ? (uint16_t)(q - f) : (uint16_t)0;
+        }
+    }
+    if (__any(violated) && lane == 0) atomicOr(status, 2u);
+}
+
 hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
-                        uint32_t window, uint16_t *far, uint16_t *next, uint64_t base, hipStream_t s) {
+                        uint32_t window, uint16_t *far, uint16_t *next, uint64_t base, uint32_t *status, bool safe,
+                        hipStream_t s) {
     if (r1 <= r0) return hipSuccess;
     const uint64_t nseg = (r1 - r0 + kIdxSegment - 1) / kIdxSegment;
-    hipLaunchKernelGGL(k_index, dim3((uint32_t)nseg), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, far,
-                       next, base);
+    if (safe)
+        hipLaunchKernelGGL(k_index, dim3((uint32_t)nseg), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, far,
+                           next, base);
+    else
+        hipLaunchKernelGGL(k_index_x, dim3((uint32_t)nseg), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window,
+                           far, next, base, status);
     return hipGetLastError();
 }
 
@@ -160,6 +261,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
                                                           uint32_t *__restrict__ match) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[kDataLds];
     __shared__ __attribute__((aligned(16))) uint16_t s_next[kNextLds];
+    __shared__ uint32_t s_counter;  // next unclaimed position of the tile
 
     const uint32_t chunk = c0 + blockIdx.x / tiles_per_chunk;
     const uint32_t tile = blockIdx.x % tiles_per_chunk;
@@ -173,6 +275,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
     const uint32_t nbytes = (uint32_t)(w1 - w0);
     const uint32_t nlinks = (uint32_t)(t1 - w0);
     const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_counter = 0;
 
     // stage bytes: 16-byte vectors when the source is aligned, bytes otherwise
     if (((reinterpret_cast<uintptr_t>(data) + w0) & 15) == 0) {
@@ -199,53 +302,127 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
     }
     __syncthreads();
 
+    // Search.  Chain lengths are very uneven (Zipf-like), so positions are not bound to threads: a lane claims
+    // the next unresolved position of the tile from an LDS counter whenever it finishes one.  Every iteration
+    // all lanes run one branch-free "head" step (first three bytes + the byte window that would have to match
+    // to beat the best length so far).  The two rarer kinds of work -- measuring a surviving candidate, and
+    // retiring a position / claiming the next one -- are deferred until enough lanes of the wave wait for them,
+    // so that each of the three code paths runs with most of its lanes active.
     const uint32_t min_len = mp.min_len, max_len = mp.max_len;
-    for (uint64_t p = t0 + tid; p < t1; p += kMatchThreads) {
-        uint32_t best = 0, bestd = 0;
-        const uint64_t remain = ce - p;
-        uint32_t cap = remain < (uint64_t)(max_len - 1) ? (uint32_t)remain : max_len - 1;
-        const uint32_t fd = far[p - base];
-        // the reference searches only while pos < len - min_len, and records nothing below min_len
-        if (fd != 0 && remain > min_len && cap >= min_len) {
-            const uint32_t po = (uint32_t)(p - w0);
-            uint32_t so = po - fd;
-            const uint32_t p0 = lds_ld4(s_data, po);
-            for (;;) {
-                const uint32_t d = po - so;
-                if (d <= min_len) break;  // loop guard: s + min_len < pos
+    const uint32_t tn = (uint32_t)(t1 - t0);
+    const uint32_t pbase = (uint32_t)(t0 - w0);  // LDS offset of tile position 0
+    const uint16_t *far_t = far + (t0 - base);
+    uint32_t *match_t = match + (t0 - base);
+    const uint64_t tail_room = ce - t0;  // bytes from tile position 0 to the end of the chunk
+
+    enum : uint32_t { HEAD = 0, EVAL = 1, FETCH = 2, DONE = 3 };
+    constexpr uint32_t kEvalBatch = 16, kFetchBatch = 8;
+    uint32_t mode = FETCH;
+    bool has_pos = false;  // a position is loaded in (idx, best, bestd) and its result is not yet written
+    uint32_t idx = 0, po = pbase, so = pbase, cap = 0, best = 0, bestd = 0, p0 = 0, p1 = 0, toff = 0, pt = 0;
+    uint32_t nxt_idx = atomicAdd(&s_counter, 1u);
+    uint32_t nxt_far = nxt_idx < tn ? far_t[nxt_idx] : 0u;
+
+    for (;;) {
+        // ---- head step (all lanes; only HEAD lanes commit) ----
+        {
+            const uint32_t d = po - so;
+            const uint32_t w0v = lds_ld4(s_data, so);
+            const uint32_t wt = lds_ld4(s_data, so + toff);
+            const uint32_t nx = s_next[so];
+            const bool guard_end = d <= min_len;                         // loop guard: s + min_len < pos
+            const bool pass3 = ((w0v ^ p0) & 0x00FFFFFFu) == 0;          // three common bytes
+            const bool passt = (best == 0) | (d <= max_len) | (wt == pt); // may end the search or beat the best
+            if (mode == HEAD) {
+                if (guard_end) {
+                    mode = FETCH;
+                } else if (pass3 & passt) {
+                    mode = EVAL;
+                } else {
+                    so += nx;
+                    if (nx == 0) mode = FETCH;
+                }
+            }
+        }
+        // ---- measure surviving candidates ----
+        uint32_t n_head = (uint32_t)__popcll(__ballot(mode == HEAD));
+        uint32_t n_eval = (uint32_t)__popcll(__ballot(mode == EVAL));
+        if (n_eval >= kEvalBatch || (n_eval != 0 && n_head == 0)) {
+            if (mode == EVAL) {
+                uint32_t m;
                 const uint32_t x0 = lds_ld4(s_data, so) ^ p0;
-                if ((x0 & 0x00FFFFFFu) == 0) {  // first three bytes agree
-                    if (d > max_len) {
-                        // cannot end the search; only a strictly longer match matters
-                        bool maybe = true;
-                        if (best >= 3) maybe = lds_ld4(s_data, so + best - 3) == lds_ld4(s_data, po + best - 3);
-                        if (maybe) {
-                            const uint32_t m = lds_lcp(s_data, so, po, cap);
-                            if (m >= min_len && m > best) {
-                                best = m;
-                                bestd = d;
-                                if (best == cap) break;
-                            }
-                        }
+                if (x0) {
+                    m = 3;
+                } else {
+                    const uint32_t x1 = lds_ld4(s_data, so + 4) ^ p1;
+                    if (x1) {
+                        m = 4 + ((uint32_t)__builtin_ctz(x1) >> 3);
                     } else {
-                        const uint32_t m = lds_lcp(s_data, so, po, cap);
-                        if (m >= min_len) {
-                            if (m + 1 >= d) break;  // the growing match reached pos: search over
-                            if (m > best) {
-                                best = m;
-                                bestd = d;
-                                if (best == cap) break;
+                        m = 8;
+                        while (m < cap) {
+                            const uint32_t x = lds_ld4(s_data, so + m) ^ lds_ld4(s_data, po + m);
+                            if (x) {
+                                m += (uint32_t)__builtin_ctz(x) >> 3;
+                                break;
                             }
+                            m += 4;
                         }
                     }
                 }
+                if (m > cap) m = cap;
+                const uint32_t d = po - so;
+                bool finish = false;
+                if (m >= min_len) {
+                    if (d <= max_len && m + 1 >= d) {  // the growing match reached pos: search over
+                        finish = true;
+                    } else if (m > best) {
+                        best = m;
+                        bestd = d;
+                        toff = best - 3;
+                        pt = lds_ld4(s_data, po + toff);
+                        finish = best == cap;  // cannot be exceeded
+                    }
+                }
                 const uint32_t nx = s_next[so];
-                if (nx == 0) break;
                 so += nx;
-                if (so >= po) break;
+                mode = (finish || nx == 0) ? FETCH : HEAD;
             }
+            n_head = (uint32_t)__popcll(__ballot(mode == HEAD));
+            n_eval = (uint32_t)__popcll(__ballot(mode == EVAL));
         }
-        match[p - base] = best ? ((best << 16) | bestd) : 0u;
+        // ---- retire finished positions and claim new ones ----
+        const uint32_t n_fetch = (uint32_t)__popcll(__ballot(mode == FETCH));
+        if (n_fetch >= kFetchBatch || (n_fetch != 0 && n_head == 0 && n_eval == 0)) {
+            if (mode == FETCH) {
+                if (has_pos) match_t[idx] = best ? ((best << 16) | bestd) : 0u;
+                has_pos = false;
+                if (nxt_idx >= tn) {
+                    mode = DONE;
+                } else {
+                    idx = nxt_idx;
+                    const uint32_t fd = nxt_far;
+                    nxt_idx = atomicAdd(&s_counter, 1u);
+                    nxt_far = nxt_idx < tn ? far_t[nxt_idx] : 0u;
+                    const uint64_t remain = tail_room - idx;
+                    cap = remain < (uint64_t)(max_len - 1) ? (uint32_t)remain : max_len - 1;
+                    best = 0;
+                    bestd = 0;
+                    has_pos = true;
+                    // the reference searches only while pos < len - min_len, and records nothing below min_len
+                    if (fd != 0 && remain > min_len && cap >= min_len) {
+                        po = pbase + idx;
+                        so = po - fd;
+                        p0 = lds_ld4(s_data, po);
+                        p1 = lds_ld4(s_data, po + 4);
+                        toff = 0;
+                        pt = p0;
+                        mode = HEAD;
+                    }
+                }
+            }
+        } else if (n_fetch == 0 && n_head == 0 && n_eval == 0) {
+            break;  // every lane is DONE
+        }
     }
 }
 
