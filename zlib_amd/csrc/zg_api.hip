@@ -62,7 +62,7 @@ struct zg_ctx {
     std::mutex mu;
     std::string err;
     DevBuf far, next, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
-        scalars, stage_in, stage_out, misc;
+        scalars, stage_in, stage_out, misc, flag, sub_exit, sub_exit2, merged, tile_cnt;
     // shard state kept between zg_shard_begin and zg_shard_finish
     bool shard_active = false;
     ChunkGrid shard_grid{};
@@ -211,8 +211,19 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
         LAUNCH(K_MATCH, launch_match(g, c0, c1, mp, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
                                      c->match.as<uint32_t>(), c->stream));
     }
-    LAUNCH(K_PARSE, launch_parse(g, c0, c1, c->match.as<uint32_t>(), ib0, c->tokens.as<uint32_t>(), bs,
-                                 c->ntok.as<uint32_t>(), c->freq.as<uint32_t>(), c->stream));
+    {
+        const uint64_t nc = c1 - c0;
+        const uint64_t spc = parse_subs_per_chunk(g.chunk_bytes), tpc = emit_tiles_per_chunk(g.chunk_bytes);
+        HIPCHK(c->flag.ensure(span + 64));
+        HIPCHK(c->sub_exit.ensure(nc * spc * 4));
+        HIPCHK(c->sub_exit2.ensure(nc * spc * 4));
+        HIPCHK(c->merged.ensure(nc * spc));
+        HIPCHK(c->tile_cnt.ensure(nc * tpc * 4));
+        LAUNCH(K_PARSE, launch_parse(g, c0, c1, c->match.as<uint32_t>(), ib0, c->flag.as<uint8_t>(), span,
+                                     c->sub_exit.as<uint32_t>(), c->sub_exit2.as<uint32_t>(), c->merged.as<uint8_t>(),
+                                     c->tile_cnt.as<uint32_t>(), c->tokens.as<uint32_t>(), bs, c->ntok.as<uint32_t>(),
+                                     c->freq.as<uint32_t>(), c->stream));
+    }
     if (want_codes)
         LAUNCH(K_HUFFMAN, launch_huffman(c1 - c0, strategy, c->freq.as<uint32_t>(), final_chunk, c->tab.as<uint32_t>(),
                                          c->hdr.as<uint32_t>(), c->hdr_bits.as<uint32_t>(),
@@ -380,7 +391,7 @@ void zg_destroy(zg_ctx *c) {
     prof_collect(c);
     DevBuf *bufs[] = {&c->far, &c->next, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
                       &c->block_bits, &c->bit_off, &c->tile_bits, &c->adler_part, &c->scalars, &c->stage_in,
-                      &c->stage_out, &c->misc};
+                      &c->stage_out, &c->misc, &c->flag, &c->sub_exit, &c->sub_exit2, &c->merged, &c->tile_cnt};
     for (DevBuf *b : bufs) b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;

@@ -1,6 +1,6 @@
 // Everything between the per-position match table and the packed bit stream:
-// greedy parse resolution + token emission + literal/length/distance
-// histograms (k_parse), per-block code construction (k_huffman), and the
+// greedy parse resolution (k_parse_*), unit emission + literal/length/distance
+// histograms (k_emit*), per-block code construction (k_huffman), and the
 // prefix-sum / scatter-pack bit writer (k_tile_bits, k_offsets, k_encode).
 #include "zg_huff_core.h"
 #include "zg_internal.h"
@@ -8,104 +8,266 @@
 namespace zg {
 
 // ---------------------------------------------------------------------------
-// k_parse: one workgroup per chunk.  The greedy parse of
-// LZ77Compressor::compress (reference src/lz77.rs:156-204) is the chain
-// pos -> pos + max(1, L(pos)); it is walked tile by tile in LDS, then all
-// threads turn the visited positions into packed LZ77 units (in order, by a
-// block-wide prefix sum of the visit flags) and count symbols with LDS
-// atomics as HuffmanTree::from_lz77 does (src/huffman.rs:243-264).
+// Greedy parse resolution.  The parse of LZ77Compressor::compress (reference
+// src/lz77.rs:156-204) is the chain pos -> pos + max(1, L(pos)) from the chunk
+// start.  It is resolved without walking the chunk serially:
+//   k_parse_spec   one lane per sub-tile of kParseSub positions walks the chain
+//                  from the sub-tile's first position (a guess for every
+//                  sub-tile but the first), flagging the positions it visits;
+//   k_parse_fix    one lane per sub-tile takes the previous sub-tile's exit as
+//                  its true entry, walks from there until it meets a flagged
+//                  position (greedy parses re-synchronise within a few units),
+//                  then swaps the flags of the guessed prefix for the true one;
+//   k_parse_check  one wave per chunk: if some sub-tile never met its guess
+//                  (long runs), everything after it is re-walked serially.
+// The exits recorded by k_parse_fix are exact as long as every earlier
+// sub-tile merged, which is what k_parse_check verifies.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kParseThreads) void k_parse(const uint8_t *__restrict__ data, uint64_t first,
-                                                          uint64_t end, uint64_t chunk_bytes, uint32_t c0,
-                                                          const uint32_t *__restrict__ match, uint64_t base,
-                                                          uint32_t *__restrict__ tokens, uint64_t tok_base,
-                                                          uint32_t *__restrict__ ntok, uint32_t *__restrict__ freq) {
-    __shared__ uint32_t s_m[kParseTile];
-    __shared__ uint8_t s_flag[kParseTile];
-    __shared__ uint32_t s_hist[kTabStride];
-    __shared__ uint32_t s_scan[kParseThreads];
-    __shared__ uint64_t s_entry;
-    __shared__ uint32_t s_ntok;
+__device__ __forceinline__ uint32_t parse_step(const uint32_t *__restrict__ match, uint64_t idx) {
+    const uint32_t len = match[idx] >> 16;
+    return len ? len : 1u;
+}
 
-    const uint32_t ci = blockIdx.x;  // index inside the batch
-    const uint32_t chunk = c0 + ci;
-    const uint64_t cs = first + (uint64_t)chunk * chunk_bytes;
+__global__ __launch_bounds__(64) void k_parse_spec(uint64_t first, uint64_t end, uint64_t chunk_bytes, uint32_t c0,
+                                                    uint32_t n_chunks, uint32_t spc,
+                                                    const uint32_t *__restrict__ match, uint64_t base,
+                                                    uint8_t *__restrict__ flag, uint32_t *__restrict__ sub_exit) {
+    const uint64_t gid = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    const uint32_t ci = (uint32_t)(gid / spc), j = (uint32_t)(gid % spc);
+    if (ci >= n_chunks) return;
+    const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
     const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
-    const uint32_t tid = threadIdx.x;
-    uint32_t *tok_out = tokens + (cs - tok_base);
+    const uint64_t s0 = cs + (uint64_t)j * kParseSub;
+    if (s0 >= ce && !(j == 0)) return;
+    const uint64_t s1 = (s0 + kParseSub < ce) ? s0 + kParseSub : ce;
+    uint64_t p = s0;
+    while (p < s1) {
+        flag[p - base] = 1;
+        p += parse_step(match, p - base);
+    }
+    sub_exit[(uint64_t)ci * spc + j] = (uint32_t)(p - cs);
+}
 
-    for (uint32_t i = tid; i < kTabStride; i += kParseThreads) s_hist[i] = 0;
+__global__ __launch_bounds__(64) void k_parse_fix(uint64_t first, uint64_t end, uint64_t chunk_bytes, uint32_t c0,
+                                                   uint32_t n_chunks, uint32_t spc,
+                                                   const uint32_t *__restrict__ match, uint64_t base,
+                                                   uint8_t *__restrict__ flag, const uint32_t *__restrict__ sub_exit,
+                                                   uint32_t *__restrict__ sub_exit2, uint8_t *__restrict__ merged) {
+    const uint64_t gid = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    const uint32_t ci = (uint32_t)(gid / spc), j = (uint32_t)(gid % spc);
+    if (ci >= n_chunks) return;
+    const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
+    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+    const uint64_t s0 = cs + (uint64_t)j * kParseSub;
+    const uint64_t k = (uint64_t)ci * spc + j;
+    if (j == 0) {
+        sub_exit2[k] = sub_exit[k];
+        merged[k] = 1;
+        return;
+    }
+    if (s0 >= ce) {
+        merged[k] = 1;
+        return;
+    }
+    const uint64_t s1 = (s0 + kParseSub < ce) ? s0 + kParseSub : ce;
+    const uint64_t e = cs + sub_exit[k - 1];  // true entry if every earlier sub-tile merged
+    if (e == s0) {
+        sub_exit2[k] = sub_exit[k];
+        merged[k] = 1;
+        return;
+    }
+    // where does the true chain meet the guessed one?
+    uint64_t t = e;
+    bool met = false;
+    while (t < s1) {
+        if (flag[t - base]) {
+            met = true;
+            break;
+        }
+        t += parse_step(match, t - base);
+    }
+    const uint64_t stop = met ? t : s1;  // flags from here on are already right (or there are none)
+    for (uint64_t s = s0; s < stop;) {   // drop the guessed prefix
+        flag[s - base] = 0;
+        s += parse_step(match, s - base);
+    }
+    for (uint64_t u = e; u < stop;) {    // put the true prefix
+        flag[u - base] = 1;
+        u += parse_step(match, u - base);
+    }
+    sub_exit2[k] = met ? sub_exit[k] : (uint32_t)(t - cs);
+    merged[k] = met ? 1 : 0;
+}
+
+__global__ __launch_bounds__(64) void k_parse_check(uint64_t first, uint64_t end, uint64_t chunk_bytes, uint32_t c0,
+                                                     uint32_t spc, const uint32_t *__restrict__ match, uint64_t base,
+                                                     uint8_t *__restrict__ flag, const uint32_t *__restrict__ sub_exit2,
+                                                     const uint8_t *__restrict__ merged) {
+    const uint32_t ci = blockIdx.x, lane = threadIdx.x;
+    const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
+    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+    const uint32_t nsub = (uint32_t)((ce - cs + kParseSub - 1) / kParseSub);
+    uint32_t bad = 0xFFFFFFFFu;  // first sub-tile that never met its guess
+    for (uint32_t j0 = 0; j0 < nsub && bad == 0xFFFFFFFFu; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const bool nm = j < nsub && !merged[(uint64_t)ci * spc + j];
+        const uint64_t b = __ballot(nm);
+        if (b) bad = j0 + (uint32_t)(__ffsll((unsigned long long)b) - 1);
+    }
+    if (bad == 0xFFFFFFFFu || bad + 1 >= nsub) return;
+    // everything after sub-tile `bad` was resolved from a wrong entry: redo it serially
+    const uint64_t r0 = cs + (uint64_t)(bad + 1) * kParseSub;
+    for (uint64_t p = r0 + lane; p < ce; p += 64) flag[p - base] = 0;
+    __syncthreads();
+    if (lane == 0) {
+        uint64_t p = cs + sub_exit2[(uint64_t)ci * spc + bad];
+        while (p < ce) {
+            flag[p - base] = 1;
+            p += parse_step(match, p - base);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Unit emission: flagged positions become packed LZ77 units, in order, and
+// are counted as HuffmanTree::from_lz77 does (src/huffman.rs:243-264).
+// k_emit_count sums the flags per tile, k_emit_scan turns the sums into
+// offsets per chunk, k_emit writes the units and the histograms.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kEmitThreads) void k_emit_count(uint64_t first, uint64_t end, uint64_t chunk_bytes,
+                                                              uint32_t c0, uint32_t tpc,
+                                                              const uint8_t *__restrict__ flag, uint64_t base,
+                                                              uint32_t *__restrict__ tile_cnt) {
+    __shared__ uint32_t s_red[kEmitThreads / 64];
+    const uint32_t ci = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
+    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+    const uint64_t t0 = cs + (uint64_t)tile * kEmitTile;
+    uint32_t cnt = 0;
+    if (t0 < ce) {
+        const uint32_t tn = (uint32_t)((ce - t0 < kEmitTile) ? ce - t0 : kEmitTile);
+        const uint8_t *f = flag + (t0 - base);
+        for (uint32_t i = tid; i < tn; i += kEmitThreads) cnt += f[i];
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((tid & 63) == 0) s_red[tid >> 6] = cnt;
+    __syncthreads();
     if (tid == 0) {
-        s_entry = cs;
-        s_ntok = 0;
+        uint32_t t = 0;
+        for (uint32_t i = 0; i < kEmitThreads / 64; i++) t += s_red[i];
+        tile_cnt[(uint64_t)ci * tpc + tile] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_emit_scan(uint32_t tpc, uint32_t *__restrict__ tile_cnt,
+                                                    uint32_t *__restrict__ ntok) {
+    __shared__ uint32_t s_part[256];
+    const uint32_t ci = blockIdx.x, tid = threadIdx.x;
+    uint32_t *tc = tile_cnt + (uint64_t)ci * tpc;
+    const uint32_t per = (tpc + 255) / 256;
+    const uint32_t lo = tid * per, hi = (lo + per < tpc) ? lo + per : tpc;
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += tc[i];
+    s_part[tid] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        const uint32_t v = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - s;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = tc[i];
+        tc[i] = run;
+        run += v;
+    }
+    if (tid == 255) ntok[ci] = s_part[255];
+}
+
+__global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict__ data, uint64_t first, uint64_t end,
+                                                        uint64_t chunk_bytes, uint32_t c0, uint32_t tpc,
+                                                        const uint8_t *__restrict__ flag,
+                                                        const uint32_t *__restrict__ match, uint64_t base,
+                                                        const uint32_t *__restrict__ tile_off,
+                                                        uint32_t *__restrict__ tokens, uint64_t tok_base,
+                                                        uint32_t *__restrict__ freq) {
+    __shared__ uint32_t s_hist[kTabStride];
+    __shared__ uint32_t s_scan[kEmitThreads];
+    const uint32_t ci = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
+    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+    const uint64_t t0 = cs + (uint64_t)tile * kEmitTile;
+    if (t0 >= ce) return;
+    const uint32_t tn = (uint32_t)((ce - t0 < kEmitTile) ? ce - t0 : kEmitTile);
+    for (uint32_t i = tid; i < kTabStride; i += kEmitThreads) s_hist[i] = 0;
+    constexpr uint32_t kPer = kEmitTile / kEmitThreads;  // consecutive positions per thread
+    const uint32_t b0 = tid * kPer;
+    const uint8_t *f = flag + (t0 - base);
+    uint32_t fl = 0, cnt = 0;  // flags of my positions as a bit mask
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; i++)
+        if (b0 + i < tn && f[b0 + i]) {
+            fl |= 1u << i;
+            cnt++;
+        }
+    s_scan[tid] = cnt;
+    __syncthreads();
+    for (uint32_t off = 1; off < kEmitThreads; off <<= 1) {
+        const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    uint32_t *tok_out = tokens + (cs - tok_base) + tile_off[(uint64_t)ci * tpc + tile] + (s_scan[tid] - cnt);
+    const uint32_t *mt = match + (t0 - base);
+    while (fl) {
+        const uint32_t i = (uint32_t)__builtin_ctz(fl);
+        fl &= fl - 1;
+        const uint32_t r = b0 + i;
+        const uint32_t mv = mt[r];
+        uint32_t tok;
+        if (mv) {
+            const uint32_t len = mv >> 16, dist = mv & 0xFFFFu;
+            tok = ZG_TOK_MARKER | (len << 16) | dist;
+            atomicAdd(&s_hist[257u + length_code_index(len)], 1u);
+            atomicAdd(&s_hist[kDOff + dist_code(dist)], 1u);
+        } else {
+            tok = data[t0 + r];
+            atomicAdd(&s_hist[tok], 1u);
+        }
+        *tok_out++ = tok;
     }
     __syncthreads();
-
-    constexpr uint32_t kPer = kParseTile / kParseThreads;  // consecutive positions per thread
-    for (uint64_t tile0 = cs; tile0 < ce; tile0 += kParseTile) {
-        const uint32_t tn = (uint32_t)((ce - tile0 < kParseTile) ? ce - tile0 : kParseTile);
-        for (uint32_t i = tid; i < tn; i += kParseThreads) {
-            s_m[i] = match[tile0 + i - base];
-            s_flag[i] = 0;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint64_t rel = s_entry - tile0;  // may already lie past this tile
-            while (rel < tn) {
-                s_flag[rel] = 1;
-                const uint32_t len = s_m[rel] >> 16;
-                rel += len ? len : 1u;
-            }
-            s_entry = tile0 + rel;
-        }
-        __syncthreads();
-        const uint32_t b0 = tid * kPer;
-        uint32_t cnt = 0;
-        for (uint32_t i = 0; i < kPer; i++)
-            if (b0 + i < tn) cnt += s_flag[b0 + i];
-        s_scan[tid] = cnt;
-        __syncthreads();
-        for (uint32_t off = 1; off < kParseThreads; off <<= 1) {  // inclusive Hillis-Steele scan
-            const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
-            __syncthreads();
-            s_scan[tid] += v;
-            __syncthreads();
-        }
-        uint32_t o = s_ntok + s_scan[tid] - cnt;
-        for (uint32_t i = 0; i < kPer; i++) {
-            const uint32_t r = b0 + i;
-            if (r < tn && s_flag[r]) {
-                const uint32_t mv = s_m[r];
-                uint32_t tok;
-                if (mv) {
-                    const uint32_t len = mv >> 16, dist = mv & 0xFFFFu;
-                    tok = ZG_TOK_MARKER | (len << 16) | dist;
-                    atomicAdd(&s_hist[257u + length_code_index(len)], 1u);
-                    atomicAdd(&s_hist[kDOff + dist_code(dist)], 1u);
-                } else {
-                    tok = data[tile0 + r];
-                    atomicAdd(&s_hist[tok], 1u);
-                }
-                tok_out[o++] = tok;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) s_ntok += s_scan[kParseThreads - 1];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        ntok[ci] = s_ntok;
-        if (s_hist[256] == 0) s_hist[256] = 1;  // "ensure terminating character is encoded", huffman.rs:264
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < kTabStride; i += kParseThreads) freq[(uint64_t)ci * kTabStride + i] = s_hist[i];
+    for (uint32_t i = tid; i < kTabStride; i += kEmitThreads)
+        if (s_hist[i]) atomicAdd(&freq[(uint64_t)ci * kTabStride + i], s_hist[i]);
 }
 
 hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint32_t *match, uint64_t base,
-                        uint32_t *tokens, uint64_t tok_base, uint32_t *ntok, uint32_t *freq, hipStream_t s) {
+                        uint8_t *flag, uint64_t flag_bytes, uint32_t *sub_exit, uint32_t *sub_exit2, uint8_t *merged,
+                        uint32_t *tile_cnt, uint32_t *tokens, uint64_t tok_base, uint32_t *ntok, uint32_t *freq,
+                        hipStream_t s) {
     if (c1 <= c0) return hipSuccess;
-    hipLaunchKernelGGL(k_parse, dim3(c1 - c0), dim3(kParseThreads), 0, s, g.data, g.first, g.end, g.chunk_bytes, c0,
-                       match, base, tokens, tok_base, ntok, freq);
+    const uint32_t nc = c1 - c0;
+    const uint32_t spc = parse_subs_per_chunk(g.chunk_bytes);
+    const uint32_t tpc = emit_tiles_per_chunk(g.chunk_bytes);
+    hipError_t e = hipMemsetAsync(flag, 0, flag_bytes, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(freq, 0, (size_t)nc * kTabStride * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    const uint64_t lanes = (uint64_t)nc * spc;
+    const uint32_t blocks = (uint32_t)((lanes + 63) / 64);
+    hipLaunchKernelGGL(k_parse_spec, dim3(blocks), dim3(64), 0, s, g.first, g.end, g.chunk_bytes, c0, nc, spc, match,
+                       base, flag, sub_exit);
+    hipLaunchKernelGGL(k_parse_fix, dim3(blocks), dim3(64), 0, s, g.first, g.end, g.chunk_bytes, c0, nc, spc, match,
+                       base, flag, sub_exit, sub_exit2, merged);
+    hipLaunchKernelGGL(k_parse_check, dim3(nc), dim3(64), 0, s, g.first, g.end, g.chunk_bytes, c0, spc, match, base,
+                       flag, sub_exit2, merged);
+    hipLaunchKernelGGL(k_emit_count, dim3(tpc, nc), dim3(kEmitThreads), 0, s, g.first, g.end, g.chunk_bytes, c0, tpc,
+                       flag, base, tile_cnt);
+    hipLaunchKernelGGL(k_emit_scan, dim3(nc), dim3(256), 0, s, tpc, tile_cnt, ntok);
+    hipLaunchKernelGGL(k_emit, dim3(tpc, nc), dim3(kEmitThreads), 0, s, g.data, g.first, g.end, g.chunk_bytes, c0, tpc,
+                       flag, match, base, tile_cnt, tokens, tok_base, freq);
     return hipGetLastError();
 }
 
@@ -164,6 +326,7 @@ __global__ __launch_bounds__(64) void k_huffman(uint32_t n_chunks, int strategy,
     for (uint32_t i = lane; i < kHdrWords; i += 64) s_hdr[i] = 0;
     __syncthreads();
     if (lane == 0) {
+        if (s_freq[256] == 0) s_freq[256] = 1;  // "ensure terminating character is encoded", src/huffman.rs:264
         uint64_t payload = 0;
         s_hbits = build_block(s_freq, s_freq + kDOff, strategy, (int64_t)c == final_chunk, s_tab, s_hdr, &payload,
                               s_work);

@@ -26,9 +26,16 @@ constexpr uint32_t kIdxSegment = 256 * 1024;  // positions owned by one index wo
 constexpr uint32_t kMatchTile = 16384;  // positions resolved by one match workgroup
 constexpr uint32_t kMatchThreads = 1024;
 
-// parse kernel geometry
-constexpr uint32_t kParseTile = 8192;
-constexpr uint32_t kParseThreads = 256;
+// parse / emit kernel geometry
+constexpr uint32_t kParseSub = 1024;   // positions per speculative parse sub-tile (> kMaxMatch)
+constexpr uint32_t kEmitTile = 4096;   // positions per unit-emission workgroup
+constexpr uint32_t kEmitThreads = 256;
+inline uint32_t parse_subs_per_chunk(uint64_t chunk_bytes) {
+    return (uint32_t)((chunk_bytes + kParseSub - 1) / kParseSub);
+}
+inline uint32_t emit_tiles_per_chunk(uint64_t chunk_bytes) {
+    return (uint32_t)((chunk_bytes + kEmitTile - 1) / kEmitTile);
+}
 
 // encode kernel geometry
 constexpr uint32_t kEncTile = 2048;  // tokens per encode workgroup
@@ -58,7 +65,9 @@ hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint6
 hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *far,
                         const uint16_t *next, uint64_t base, uint32_t *match, hipStream_t s);
 hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint32_t *match, uint64_t base,
-                        uint32_t *tokens, uint64_t tok_base, uint32_t *ntok, uint32_t *freq, hipStream_t s);
+                        uint8_t *flag, uint64_t flag_bytes, uint32_t *sub_exit, uint32_t *sub_exit2, uint8_t *merged,
+                        uint32_t *tile_cnt, uint32_t *tokens, uint64_t tok_base, uint32_t *ntok, uint32_t *freq,
+                        hipStream_t s);
 hipError_t launch_histogram(const uint32_t *tokens, uint64_t n, uint32_t *freq, hipStream_t s);
 hipError_t launch_huffman(uint32_t n_chunks, int strategy, const uint32_t *freq, int64_t final_chunk, uint32_t *tab,
                           uint32_t *hdr, uint32_t *hdr_bits, uint64_t *block_bits, hipStream_t s);
