@@ -112,6 +112,22 @@ def test_streams_corpora(za, z, kind, n, chunk):
     assert z.decompress(got) == data
 
 
+def test_long_runs_and_periodic_data(za, z):
+    """Inputs whose parse units are long: the speculative parse cannot re-synchronise inside a sub-tile and the
+    serial re-walk has to take over; the match search hits its early-outs."""
+    rng = random.Random(17)
+    rec = bytes(rng.randrange(256) for _ in range(16))
+    cases = [bytes(70_000), b"\x07" * 33_000 + bytes(40_000), rec * 5000, (b"ab" * 600 + b"c") * 60,
+             bytes(rng.randrange(2) for _ in range(60_000)), b"abcdefgh" * 9000 + bytes(rng.randrange(256) for _ in range(5000))]
+    comp = za.zlib_compressor()
+    for data in cases:
+        assert comp.compress_packed(data) == z.lz77_zlib(data, fast=True)
+        for chunk in (1 << 20, 16384):
+            got = za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk)
+            assert got == z.compress_chunked(data, z.DYNAMIC, chunk, fast=True)
+            assert sysz.decompress(got) == data
+
+
 def test_batching_does_not_change_the_stream(za):
     data = za.corpus("text", 700_000)
     a = za.compress(data, za.Strategy.Dynamic, chunk_bytes=65536)

@@ -17,6 +17,10 @@
 // visits every relevant candidate in the reference's order.
 #include "zg_internal.h"
 
+#ifndef ZG_MATCH_STEPS
+#define ZG_MATCH_STEPS 8
+#endif
+
 namespace zg {
 
 // ---------------------------------------------------------------------------
@@ -259,9 +263,11 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
                                                           const uint16_t *__restrict__ far,
                                                           const uint16_t *__restrict__ next, uint64_t base,
                                                           uint32_t *__restrict__ match) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_data[kDataLds];
-    __shared__ __attribute__((aligned(16))) uint16_t s_next[kNextLds];
+    // one LDS image: bytes first (so that byte reads need no base add), links behind them
+    __shared__ __attribute__((aligned(16))) uint8_t s_mem[kDataLds + 2 * kNextLds];
     __shared__ uint32_t s_counter;  // next unclaimed position of the tile
+    uint8_t *const s_data = s_mem;
+    uint16_t *const s_next = reinterpret_cast<uint16_t *>(s_mem + kDataLds);
 
     const uint32_t chunk = c0 + blockIdx.x / tiles_per_chunk;
     const uint32_t tile = blockIdx.x % tiles_per_chunk;
@@ -304,10 +310,13 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
 
     // Search.  Chain lengths are very uneven (Zipf-like), so positions are not bound to threads: a lane claims
     // the next unresolved position of the tile from an LDS counter whenever it finishes one.  Every iteration
-    // all lanes run one branch-free "head" step (first three bytes + the byte window that would have to match
-    // to beat the best length so far).  The two rarer kinds of work -- measuring a surviving candidate, and
-    // retiring a position / claiming the next one -- are deferred until enough lanes of the wave wait for them,
-    // so that each of the three code paths runs with most of its lanes active.
+    // all lanes run kHeadSteps branch-free "head" steps: one four-byte probe of the candidate and its forward
+    // link.  The probe looks at the only place that can still matter: for a candidate too far away to end the
+    // search, the four bytes ending at offset `best` (they must all agree for it to beat the best length so
+    // far); for a candidate within max_len of the position, or while nothing has been found, the first three
+    // bytes.  The two rarer kinds of work -- measuring a candidate that survived the probe, and retiring a
+    // position / claiming the next one -- are deferred until enough lanes of the wave wait for them, so that
+    // each of the three code paths runs with most of its lanes active.
     const uint32_t min_len = mp.min_len, max_len = mp.max_len;
     const uint32_t tn = (uint32_t)(t1 - t0);
     const uint32_t pbase = (uint32_t)(t0 - w0);  // LDS offset of tile position 0
@@ -316,43 +325,42 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
     const uint64_t tail_room = ce - t0;  // bytes from tile position 0 to the end of the chunk
 
     enum : uint32_t { HEAD = 0, EVAL = 1, FETCH = 2, DONE = 3 };
+    constexpr int kHeadSteps = ZG_MATCH_STEPS;  // head steps between checks of the deferred work
     constexpr uint32_t kEvalBatch = 16, kFetchBatch = 8;
-    uint32_t mode = FETCH;
-    bool has_pos = false;  // a position is loaded in (idx, best, bestd) and its result is not yet written
-    uint32_t idx = 0, po = pbase, so = pbase, cap = 0, best = 0, bestd = 0, p0 = 0, p1 = 0, toff = 0, pt = 0;
+    uint32_t mode = FETCH, idx = 0, po = pbase, so = pbase, cap = 0, best = 0, bestd = 0, p0 = 0, p1 = 0;
+    uint32_t toff = 0, pt = 0, tmask = 0x00FFFFFFu;  // far-candidate probe: offset, expected bytes, byte mask
+    bool has_pos = false;  // a position is loaded and its result is not yet written
     uint32_t nxt_idx = atomicAdd(&s_counter, 1u);
     uint32_t nxt_far = nxt_idx < tn ? far_t[nxt_idx] : 0u;
 
     for (;;) {
-        // ---- head step (all lanes; only HEAD lanes commit) ----
-        {
+#pragma unroll
+        for (int step = 0; step < kHeadSteps; step++) {
             const uint32_t d = po - so;
-            const uint32_t w0v = lds_ld4(s_data, so);
-            const uint32_t wt = lds_ld4(s_data, so + toff);
+            const bool nearby = d <= max_len;  // may end the search: its first bytes decide
+            const uint32_t off = nearby ? 0u : toff;
+            const uint32_t want = nearby ? p0 : pt;
+            const uint32_t msk = nearby ? 0x00FFFFFFu : tmask;
+            const uint32_t w = lds_ld4(s_data, so + off);
             const uint32_t nx = s_next[so];
-            const bool guard_end = d <= min_len;                         // loop guard: s + min_len < pos
-            const bool pass3 = ((w0v ^ p0) & 0x00FFFFFFu) == 0;          // three common bytes
-            const bool passt = (best == 0) | (d <= max_len) | (wt == pt); // may end the search or beat the best
-            if (mode == HEAD) {
-                if (guard_end) {
-                    mode = FETCH;
-                } else if (pass3 & passt) {
-                    mode = EVAL;
-                } else {
-                    so += nx;
-                    if (nx == 0) mode = FETCH;
-                }
-            }
+            const bool is_head = mode == HEAD;
+            const bool guard_end = d <= min_len;  // loop guard: s + min_len < pos
+            const bool survive = ((w ^ want) & msk) == 0;
+            const bool to_adv = is_head & !guard_end & !survive;
+            const bool to_fetch = is_head & (guard_end | (!survive & (nx == 0)));
+            const bool to_eval = is_head & !guard_end & survive;
+            so = to_adv ? so + nx : so;
+            mode = to_fetch ? (uint32_t)FETCH : (to_eval ? (uint32_t)EVAL : mode);
         }
-        // ---- measure surviving candidates ----
         uint32_t n_head = (uint32_t)__popcll(__ballot(mode == HEAD));
         uint32_t n_eval = (uint32_t)__popcll(__ballot(mode == EVAL));
+        // ---- measure surviving candidates ----
         if (n_eval >= kEvalBatch || (n_eval != 0 && n_head == 0)) {
             if (mode == EVAL) {
                 uint32_t m;
                 const uint32_t x0 = lds_ld4(s_data, so) ^ p0;
                 if (x0) {
-                    m = 3;
+                    m = (uint32_t)__builtin_ctz(x0) >> 3;
                 } else {
                     const uint32_t x1 = lds_ld4(s_data, so + 4) ^ p1;
                     if (x1) {
@@ -378,9 +386,10 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
                     } else if (m > best) {
                         best = m;
                         bestd = d;
-                        toff = best - 3;
+                        toff = m - 3;
                         pt = lds_ld4(s_data, po + toff);
-                        finish = best == cap;  // cannot be exceeded
+                        tmask = 0xFFFFFFFFu;
+                        finish = m == cap;  // cannot be exceeded
                     }
                 }
                 const uint32_t nx = s_next[so];
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
                 mode = (finish || nx == 0) ? FETCH : HEAD;
             }
             n_head = (uint32_t)__popcll(__ballot(mode == HEAD));
-            n_eval = (uint32_t)__popcll(__ballot(mode == EVAL));
+            n_eval = 0;
         }
         // ---- retire finished positions and claim new ones ----
         const uint32_t n_fetch = (uint32_t)__popcll(__ballot(mode == FETCH));
@@ -416,6 +425,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
                         p1 = lds_ld4(s_data, po + 4);
                         toff = 0;
                         pt = p0;
+                        tmask = 0x00FFFFFFu;
                         mode = HEAD;
                     }
                 }
