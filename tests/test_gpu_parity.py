@@ -9,6 +9,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def za():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.zeros(1, device="cuda")  # bring torch's HIP context up before the library's
     import zlib_amd
     zlib_amd.default_context()
     return zlib_amd
@@ -140,3 +143,35 @@ def test_raw_large(za, z):
     got = za.compress(data, za.Strategy.Raw)
     assert got == z.compress_chunked(data, z.RAW, 1 << 20)
     assert sysz.decompress(got) == data
+
+
+@pytest.mark.parametrize("world,total,chunk", [(2, 300_000, 65536), (3, 200_000, 16384), (4, 4 << 20, 1 << 20)])
+def test_shard_api_assembles_the_single_gpu_stream(za, world, total, chunk):
+    """zg_shard_begin / zg_shard_finish for every rank's run of chunks (run one after the other on this GPU),
+    assembled with the host logic the multi-GPU bench uses, give the stream of a single compress call."""
+    import torch
+    from zlib_amd import sharding
+    data = za.corpus("mixed" if total > (1 << 20) else "text", total, seed=21)
+    whole = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    plan = sharding.plan_shards(total, chunk, world)
+    engines, infos = [], []
+    for r, (start, n, halo) in enumerate(plan):
+        ctx = za.Context(0)
+        view = whole[start - halo:start + n].clone()  # the rank's own copy: halo bytes, then its run
+        out = torch.zeros(za.compress_bound(n, za.Strategy.Dynamic, chunk_bytes=chunk) + 8, dtype=torch.uint8, device="cuda")
+        eng = sharding.HipEngine(ctx, view.data_ptr(), halo, n, za.Strategy.Dynamic, chunk, out)
+        eng._keep = view
+        engines.append(eng)
+        infos.append(eng.begin(r == world - 1))
+    bases, end_bit, adler = sharding.stream_layout(infos)
+    total_bytes = (end_bit + 7) // 8 + 4
+    final = bytearray(total_bytes)
+    for r, eng in enumerate(engines):
+        nb = eng.finish(bases[r], r == 0, r == world - 1, adler)
+        piece = eng.out[:nb].cpu().numpy().tobytes()
+        off = 0 if r == 0 else bases[r] // 8
+        for i, v in enumerate(piece[:1]):
+            final[off + i] |= v
+        final[off + 1:off + nb] = piece[1:]
+    assert bytes(final) == za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk)
+    assert sysz.decompress(bytes(final)) == data

@@ -1,0 +1,106 @@
+"""Multi-GPU assembly of one zlib stream from per-rank runs of chunks.
+
+The input is cut into contiguous runs of whole chunks, one run per rank
+(SURVEY: chunks are independent given the 32 KiB of input before them).  The
+only exchange is:
+
+  1. one all_gather of three integers per rank (block bit total, Adler-32 of
+     the rank's bytes, byte count), from which every rank derives the absolute
+     bit offset of its first block and the stream's Adler-32;
+  2. a point-to-point send of each rank's packed bytes to rank 0, which ORs
+     the single byte two neighbouring ranks share when a rank starts in the
+     middle of a byte.
+
+The compute is behind an `engine` object with two calls, so that the same
+assembly logic runs over RCCL with the HIP engine (HipEngine) and over gloo on
+the CPU with a stand-in engine in the tests.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+from . import api
+
+ADLER_INIT = 1
+ZLIB_HEADER_BITS = 16
+
+
+def plan_shards(total_bytes: int, chunk_bytes: int, world: int) -> List[Tuple[int, int, int]]:
+    """(start, n, halo) per rank: contiguous runs of whole chunks (the last run takes the ragged tail)."""
+    n_chunks = max(1, -(-total_bytes // chunk_bytes))
+    out = []
+    for r in range(world):
+        c0, c1 = (r * n_chunks) // world, ((r + 1) * n_chunks) // world
+        start = min(total_bytes, c0 * chunk_bytes)
+        end = min(total_bytes, c1 * chunk_bytes)
+        out.append((start, end - start, min(32768, start)))
+    return out
+
+
+def stream_layout(infos: List[Tuple[int, int, int]]):
+    """From the gathered (total_bits, adler, n_bytes) of every rank: first-block bit offset per rank, the
+    end bit of the last block, and the Adler-32 of the whole input."""
+    base, adler, bases = ZLIB_HEADER_BITS, ADLER_INIT, []
+    for bits, ad, nbytes in infos:
+        bases.append(base)
+        base += bits
+        adler = api.adler32_combine(adler, ad, nbytes)
+    return bases, base, adler
+
+
+class HipEngine:
+    """The product engine: zg_shard_begin / zg_shard_finish on this rank's GPU."""
+
+    def __init__(self, ctx, d_in_ptr: int, halo: int, n: int, strategy, chunk_bytes: int, out_tensor):
+        self.ctx, self.d_in, self.halo, self.n = ctx, d_in_ptr, halo, n
+        self.strategy, self.chunk_bytes, self.out = strategy, chunk_bytes, out_tensor
+
+    def begin(self, last_rank: bool):
+        info = api.shard_begin(self.d_in, self.halo, self.n, self.strategy, last_rank, chunk_bytes=self.chunk_bytes,
+                               ctx=self.ctx)
+        return info.total_bits, info.adler, self.n
+
+    def finish(self, base_bit: int, first_rank: bool, last_rank: bool, adler: int) -> int:
+        return api.shard_finish(base_bit, first_rank, last_rank, adler, self.out.data_ptr(), self.out.numel(),
+                                ctx=self.ctx)
+
+
+def compress_sharded(engine, dist, torch, rank: int, world: int, device, final=None, scratch=None):
+    """One sharded compress.  Returns the stream length in bytes; on rank 0 `final[:length]` holds the
+    stream.  `engine.out` is the rank's own output tensor (uint8)."""
+    first, last = rank == 0, rank == world - 1
+    bits, ad, nbytes = engine.begin(last)
+    if scratch is None:
+        scratch = {}
+    local = scratch.setdefault("local", torch.zeros(3, dtype=torch.int64, device=device))
+    gathered = scratch.setdefault("all", torch.zeros(3 * world, dtype=torch.int64, device=device))
+    edge = scratch.setdefault("edge", torch.zeros(1, dtype=torch.uint8, device=device))
+    local.copy_(torch.tensor([bits, ad, nbytes], dtype=torch.int64))
+    try:
+        dist.all_gather_into_tensor(gathered, local)  # the one collective of the path
+    except (RuntimeError, NotImplementedError):  # backends without the flat form (older gloo)
+        parts = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(parts, local)
+        gathered.copy_(torch.cat(parts))
+    infos = [tuple(int(v) for v in row) for row in gathered.view(world, 3).tolist()]
+    bases, end_bit, adler = stream_layout(infos)
+    nb = engine.finish(bases[rank], first, last, adler)
+    total_bytes = (end_bit + 7) // 8 + 4
+    out = engine.out
+    if first:
+        final[:nb].copy_(out[:nb])
+        for r in range(1, world):
+            off = bases[r] // 8
+            stop = total_bytes if r == world - 1 else (bases[r + 1] + 7) // 8
+            dist.recv(edge, src=r)
+            if bases[r] % 8:
+                final[off] |= edge[0]  # the byte two neighbouring ranks share
+            else:
+                final[off] = edge[0]
+            if stop - off > 1:
+                dist.recv(final[off + 1:stop], src=r)
+    else:
+        dist.send(out[0:1].contiguous(), dst=0)
+        if nb > 1:
+            dist.send(out[1:nb], dst=0)
+    return total_bytes
