@@ -30,11 +30,13 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
 WORKLOADS = {
-    # name: (corpus kind, bytes per GPU, chunk bytes, seed)
-    "text64m": ("text", 64 << 20, 1 << 20, 0x5EED0001),
-    "mixed8g": ("mixed", 8 << 30, 1 << 20, 0x5EED0004),
-    "mixed1g": ("mixed", 1 << 30, 1 << 20, 0x5EED0004),
-    "text1g": ("text", 1 << 30, 1 << 20, 0x5EED0001),
+    # name: (corpus kind, bytes per GPU, chunk bytes, seed, strategy)
+    "text64m": ("text", 64 << 20, 1 << 20, 0x5EED0001, "Dynamic"),   # BASELINE.json configs[1]
+    "mixed8g": ("mixed", 8 << 30, 1 << 20, 0x5EED0004, "Dynamic"),   # configs[3] on one GPU
+    "mixed1g": ("mixed", 1 << 30, 1 << 20, 0x5EED0004, "Dynamic"),   # configs[3] at 8 GPUs (1 GiB each)
+    "text1g": ("text", 1 << 30, 1 << 20, 0x5EED0001, "Dynamic"),
+    "raw4g": ("random", 4 << 30, 1 << 20, 0x5EED0003, "Raw"),        # configs[2]: stored blocks + Adler-32
+    "raw1g": ("random", 1 << 30, 1 << 20, 0x5EED0003, "Raw"),
 }
 
 
@@ -102,7 +104,7 @@ def main():
     import zlib_amd as za
     from zlib_amd import sharding
 
-    kind, per_gpu, chunk, seed = WORKLOADS[args.workload]
+    kind, per_gpu, chunk, seed, strat_name = WORKLOADS[args.workload]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -119,8 +121,10 @@ def main():
     ctx = za.Context(local_rank)
     start, n, halo = sharding.plan_shards(total, chunk, world)[rank]
     d_in = upload_corpus(torch, za, kind, seed, start - halo, halo + n, device)
-    strategy = za.Strategy.Dynamic
+    strategy = getattr(za.Strategy, strat_name)
     final = None
+    if world > 1 and strat_name != "Dynamic":
+        raise SystemExit("the sharded path covers Dynamic/Fixed blocks only")
 
     if world == 1:
         cap = za.compress_bound(n, strategy, chunk_bytes=chunk)
@@ -184,10 +188,10 @@ def main():
         bytes_per_launch = n * (1.0 + ratio) / max(1.0, launches_per_step)  # this rank's share
         achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9
         line = {
-            "metric": "compress input GB/s (Dynamic)", "value": value, "unit": "GB/s", "n_gpus": world,
+            "metric": f"compress input GB/s ({strat_name})", "value": value, "unit": "GB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"Strategy::Dynamic on {total >> 20} MiB synthetic {kind} ({per_gpu >> 20} MiB per GPU), "
+            "config": {"workload": f"Strategy::{strat_name} on {total >> 20} MiB synthetic {kind} ({per_gpu >> 20} MiB per GPU), "
                                    f"{chunk >> 10} KiB chunks with 32 KiB window, {world} MI355X",
                        "name": args.workload, "chunk_bytes": chunk,
                        "total_bytes": total, "compressed_bytes": out_n, "ratio": ratio,
@@ -201,7 +205,7 @@ def main():
                          "note": "algorithmic bytes = input bytes read once + compressed bytes written once"},
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and strat_name == "Dynamic":
             line["cpu_baseline"] = cpu_baseline(za, kind, seed, total, chunk)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -62,7 +62,7 @@ struct zg_ctx {
     std::mutex mu;
     std::string err;
     DevBuf far, next, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
-        scalars, stage_in, stage_out, misc, flag, sub_exit, sub_exit2, merged, tile_cnt;
+        scalars, stage_in, stage_out, misc, flag, sub_exit, sub_exit2, merged, tile_cnt, adler_blk;
     // shard state kept between zg_shard_begin and zg_shard_finish
     bool shard_active = false;
     ChunkGrid shard_grid{};
@@ -255,8 +255,10 @@ int run_adler(zg_ctx *c, const uint8_t *data, uint64_t n) {
     Scalars *sc = c->scalars.as<Scalars>();
     const uint64_t nseg = (n + seg - 1) / seg;
     HIPCHK(c->adler_part.ensure(nseg * 2 * sizeof(uint32_t)));
+    HIPCHK(c->adler_blk.ensure((nseg / 1024 + 1) * 3 * sizeof(uint64_t)));
     LAUNCH(K_ADLER, launch_adler(data, n, seg, (uint32_t)nseg, c->adler_part.as<uint32_t>(), c->stream));
-    LAUNCH(K_ADLER, launch_adler_fold(c->adler_part.as<uint32_t>(), n, seg, (uint32_t)nseg, sc->adler, c->stream));
+    LAUNCH(K_ADLER, launch_adler_fold(c->adler_part.as<uint32_t>(), n, seg, (uint32_t)nseg, c->adler_blk.as<uint64_t>(),
+                                      sc->adler, c->stream));
     return ZG_OK;
 }
 
@@ -298,9 +300,13 @@ int compress_device_once(zg_ctx *c, const uint8_t *d_in, size_t n, int strategy,
     Scalars *sc = c->scalars.as<Scalars>();
 
     if (strategy == ZG_RAW) {
-        LAUNCH(K_STORED, launch_stored(d_in, n, d_out, c->stream));
-        rc = run_adler(c, d_in, n);
-        if (rc) return rc;
+        const uint64_t nblk = n == 0 ? 1 : (n + kStoredBlock - 1) / kStoredBlock;
+        HIPCHK(c->adler_part.ensure(nblk * 2 * sizeof(uint32_t)));
+        HIPCHK(c->adler_blk.ensure((nblk / 1024 + 1) * 3 * sizeof(uint64_t)));
+        LAUNCH(K_STORED, launch_stored(d_in, n, d_out, c->adler_part.as<uint32_t>(), c->stream));
+        if (n)  // the stored-block kernel left one Adler part per 16 KiB block
+            LAUNCH(K_ADLER, launch_adler_fold(c->adler_part.as<uint32_t>(), n, kStoredBlock, (uint32_t)nblk,
+                                              c->adler_blk.as<uint64_t>(), sc->adler, c->stream));
         const uint64_t bits = (uint64_t)(stored_size(n) - 4) * 8;
         HIPCHK(hipMemcpyAsync(&sc->carry, &bits, sizeof bits, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -391,7 +397,8 @@ void zg_destroy(zg_ctx *c) {
     prof_collect(c);
     DevBuf *bufs[] = {&c->far, &c->next, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
                       &c->block_bits, &c->bit_off, &c->tile_bits, &c->adler_part, &c->scalars, &c->stage_in,
-                      &c->stage_out, &c->misc, &c->flag, &c->sub_exit, &c->sub_exit2, &c->merged, &c->tile_cnt};
+                      &c->stage_out, &c->misc, &c->flag, &c->sub_exit, &c->sub_exit2, &c->merged, &c->tile_cnt,
+                      &c->adler_blk};
     for (DevBuf *b : bufs) b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;

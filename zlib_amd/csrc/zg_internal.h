@@ -84,8 +84,9 @@ hipError_t launch_encode(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *
 hipError_t launch_adler(const uint8_t *data, uint64_t n, uint64_t seg_bytes, uint32_t n_seg, uint32_t *partial,
                         hipStream_t s);
 hipError_t launch_adler_fold(const uint32_t *partial, uint64_t n, uint64_t seg_bytes, uint32_t n_seg,
-                             uint32_t *state /* [a, b] running */, hipStream_t s);
-hipError_t launch_stored(const uint8_t *data, uint64_t n, uint8_t *out, hipStream_t s);
+                             uint64_t *block_part /* 3 words per 1024 segments */, uint32_t *state /* [a, b] running */,
+                             hipStream_t s);
+hipError_t launch_stored(const uint8_t *data, uint64_t n, uint8_t *out, uint32_t *partial, hipStream_t s);
 hipError_t launch_trailer(uint8_t *out, const uint64_t *total_bits, const uint32_t *adler_state,
                           uint32_t adler_override, int use_override, int write_header, int write_adler,
                           uint64_t *out_bytes, hipStream_t s);

@@ -67,22 +67,64 @@ __global__ __launch_bounds__(256) void k_adler(const uint8_t *__restrict__ data,
     }
 }
 
-// Folds the segment values into the running (a, b) in order:
-// (a1,b1) then a segment (a2,b2) of length L gives a = a1 + a2 - 1,
-// b = b1 + b2 + L * (a1 - 1), all mod 65521.
-__global__ void k_adler_fold(const uint32_t *__restrict__ partial, uint64_t n, uint64_t seg_bytes, uint32_t n_seg,
-                             uint32_t *state) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint64_t a = state[0], b = state[1];
-    for (uint32_t i = 0; i < n_seg; i++) {
+// Folds the segment values into the running (a, b) in order: (a1,b1) followed by a segment (a2,b2) of length L
+// gives a = a1 + a2 - 1, b = b1 + b2 + L * (a1 - 1), all mod 65521.  The rule is associative, so the fold is a
+// two-stage ordered tree.
+struct AdlerPart {
+    uint64_t a, b, len;  // a, b as for a stream that starts at (1, 0); len mod 65521
+};
+__device__ __forceinline__ AdlerPart adler_join(AdlerPart x, AdlerPart y) {
+    AdlerPart r;
+    r.b = (x.b + y.b + (y.len % kAdlerMod) * ((x.a + kAdlerMod - 1) % kAdlerMod)) % kAdlerMod;
+    r.a = (x.a + y.a + kAdlerMod - 1) % kAdlerMod;
+    r.len = (x.len + y.len) % kAdlerMod;
+    return r;
+}
+// stage 1: every block joins 1024 consecutive segments (4 per thread, then an ordered tree over the block)
+__global__ __launch_bounds__(256) void k_adler_fold1(const uint32_t *__restrict__ partial, uint64_t n,
+                                                      uint64_t seg_bytes, uint32_t n_seg, uint64_t *block_part) {
+    __shared__ AdlerPart s_part[256];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lo = (blockIdx.x * 256 + tid) * 4;
+    AdlerPart acc{1, 0, 0};
+    for (uint32_t i = lo; i < lo + 4 && i < n_seg; i++) {
         const uint64_t s0 = (uint64_t)i * seg_bytes;
         const uint64_t len = (s0 + seg_bytes < n) ? seg_bytes : n - s0;
-        const uint64_t a2 = partial[2 * i], b2 = partial[2 * i + 1];
-        b = (b + b2 + (len % kAdlerMod) * ((a + kAdlerMod - 1) % kAdlerMod)) % kAdlerMod;
-        a = (a + a2 + kAdlerMod - 1) % kAdlerMod;
+        acc = adler_join(acc, AdlerPart{partial[2 * i], partial[2 * i + 1], len});
     }
-    state[0] = (uint32_t)a;
-    state[1] = (uint32_t)b;
+    s_part[tid] = acc;
+    __syncthreads();
+    for (uint32_t stride = 1; stride < 256; stride <<= 1) {
+        if ((tid & (2 * stride - 1)) == 0) s_part[tid] = adler_join(s_part[tid], s_part[tid + stride]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        block_part[3 * blockIdx.x] = s_part[0].a;
+        block_part[3 * blockIdx.x + 1] = s_part[0].b;
+        block_part[3 * blockIdx.x + 2] = s_part[0].len;
+    }
+}
+// stage 2: one block joins the block results behind the running state
+__global__ __launch_bounds__(256) void k_adler_fold2(const uint64_t *__restrict__ block_part, uint32_t n_blocks,
+                                                      uint32_t *state) {
+    __shared__ AdlerPart s_part[256];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_blocks + 255) / 256;
+    const uint32_t lo = tid * per, hi = (lo + per < n_blocks) ? lo + per : n_blocks;
+    AdlerPart acc{1, 0, 0};
+    for (uint32_t i = lo; i < hi; i++)
+        acc = adler_join(acc, AdlerPart{block_part[3 * i], block_part[3 * i + 1], block_part[3 * i + 2]});
+    s_part[tid] = acc;
+    __syncthreads();
+    for (uint32_t stride = 1; stride < 256; stride <<= 1) {
+        if ((tid & (2 * stride - 1)) == 0) s_part[tid] = adler_join(s_part[tid], s_part[tid + stride]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const AdlerPart run = adler_join(AdlerPart{state[0], state[1], 0}, s_part[0]);
+        state[0] = (uint32_t)run.a;
+        state[1] = (uint32_t)run.b;
+    }
 }
 
 hipError_t launch_adler(const uint8_t *data, uint64_t n, uint64_t seg_bytes, uint32_t n_seg, uint32_t *partial,
@@ -92,21 +134,24 @@ hipError_t launch_adler(const uint8_t *data, uint64_t n, uint64_t seg_bytes, uin
     return hipGetLastError();
 }
 hipError_t launch_adler_fold(const uint32_t *partial, uint64_t n, uint64_t seg_bytes, uint32_t n_seg,
-                             uint32_t *state, hipStream_t s) {
+                             uint64_t *block_part, uint32_t *state, hipStream_t s) {
     if (!n_seg) return hipSuccess;
-    hipLaunchKernelGGL(k_adler_fold, dim3(1), dim3(64), 0, s, partial, n, seg_bytes, n_seg, state);
+    const uint32_t nb = (n_seg + 1023) / 1024;
+    hipLaunchKernelGGL(k_adler_fold1, dim3(nb), dim3(256), 0, s, partial, n, seg_bytes, n_seg, block_part);
+    hipLaunchKernelGGL(k_adler_fold2, dim3(1), dim3(256), 0, s, block_part, nb, state);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
 // k_stored: Strategy::Raw (reference src/compress.rs:172-195 with LEN = the
 // block's own length): block b copies input [b*16384, ...) behind a five-byte
-// header at output offset 2 + b*16389.  One workgroup per stored block; the
-// destination is written in aligned dwords assembled from two aligned source
-// dwords.
+// header at output offset 2 + b*16389, and its Adler-32 part is taken from the
+// same registers (the input is read once).  One workgroup per stored block:
+// aligned 16-byte loads, 16-byte stores at the destination's own alignment.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_stored(const uint8_t *__restrict__ data, uint64_t n, uint32_t n_blocks,
-                                                 uint8_t *__restrict__ out) {
+                                                 uint8_t *__restrict__ out, uint32_t *__restrict__ partial) {
+    __shared__ uint64_t s_s1[4], s_t[4];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint64_t in0 = (uint64_t)b * kStoredBlock;
     const uint32_t len = (uint32_t)((in0 + kStoredBlock < n) ? kStoredBlock : n - in0);
@@ -120,29 +165,61 @@ __global__ __launch_bounds__(256) void k_stored(const uint8_t *__restrict__ data
     }
     uint8_t *dst = o + 5;
     const uint8_t *src = data + in0;
-    // leading bytes up to the first aligned destination dword
-    const uint32_t head = (uint32_t)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3);
-    const uint32_t h = head < len ? head : len;
-    if (tid < h) dst[tid] = src[tid];
-    const uint32_t nw = (len - h) >> 2;  // whole destination dwords
-    const uintptr_t sa = reinterpret_cast<uintptr_t>(src + h);
-    const uint32_t sh = (uint32_t)(sa & 3);
-    const uint32_t *sw = reinterpret_cast<const uint32_t *>(sa & ~(uintptr_t)3);
-    uint32_t *dw = reinterpret_cast<uint32_t *>(dst + h);
-    if (sh == 0) {
-        for (uint32_t i = tid; i < nw; i += 256) dw[i] = sw[i];
+    uint64_t s1 = 0, t = 0;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const uint4 *v = reinterpret_cast<const uint4 *>(src);
+        const uint32_t nv = len >> 4;
+        for (uint32_t i = tid; i < nv; i += 256) {
+            const uint4 q = v[i];
+            __builtin_memcpy(dst + ((uint64_t)i << 4), &q, 16);  // unaligned 16-byte store
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            uint32_t ls = 0, lt = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t b0 = w[k] & 0xFF, b1 = (w[k] >> 8) & 0xFF, b2 = (w[k] >> 16) & 0xFF, b3 = w[k] >> 24;
+                ls += b0 + b1 + b2 + b3;
+                lt += (4 * k) * b0 + (4 * k + 1) * b1 + (4 * k + 2) * b2 + (4 * k + 3) * b3;
+            }
+            s1 += ls;
+            t += (uint64_t)(i << 4) * ls + lt;
+        }
+        for (uint32_t i = (nv << 4) + tid; i < len; i += 256) {
+            const uint8_t x = src[i];
+            dst[i] = x;
+            s1 += x;
+            t += (uint64_t)i * x;
+        }
     } else {
-        // the last source dword touched is sw[nw], which holds bytes of this block (len - h - 4*nw < 4 tail
-        // bytes or the start of the next block / padding) and is inside the allocation when n is padded
-        for (uint32_t i = tid; i < nw; i += 256) dw[i] = __builtin_amdgcn_alignbyte(sw[i + 1], sw[i], sh);
+        for (uint32_t i = tid; i < len; i += 256) {
+            const uint8_t x = src[i];
+            dst[i] = x;
+            s1 += x;
+            t += (uint64_t)i * x;
+        }
     }
-    const uint32_t done = h + (nw << 2);
-    if (tid < len - done) dst[done + tid] = src[done + tid];
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off);
+        t += __shfl_down(t, off);
+    }
+    if ((tid & 63) == 0) {
+        s_s1[tid >> 6] = s1;
+        s_t[tid >> 6] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        s1 = s_s1[0] + s_s1[1] + s_s1[2] + s_s1[3];
+        t = s_t[0] + s_t[1] + s_t[2] + s_t[3];
+        const uint64_t a = (1 + s1) % kAdlerMod;
+        const uint64_t bb = (len % kAdlerMod + ((len % kAdlerMod) * (s1 % kAdlerMod)) % kAdlerMod + kAdlerMod -
+                             t % kAdlerMod) % kAdlerMod;
+        partial[2 * b] = (uint32_t)a;
+        partial[2 * b + 1] = (uint32_t)bb;
+    }
 }
 
-hipError_t launch_stored(const uint8_t *data, uint64_t n, uint8_t *out, hipStream_t s) {
+hipError_t launch_stored(const uint8_t *data, uint64_t n, uint8_t *out, uint32_t *partial, hipStream_t s) {
     const uint64_t nb = n == 0 ? 1 : (n + kStoredBlock - 1) / kStoredBlock;
-    hipLaunchKernelGGL(k_stored, dim3((uint32_t)nb), dim3(256), 0, s, data, n, (uint32_t)nb, out);
+    hipLaunchKernelGGL(k_stored, dim3((uint32_t)nb), dim3(256), 0, s, data, n, (uint32_t)nb, out, partial);
     return hipGetLastError();
 }
 
