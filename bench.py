@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
 WORKLOADS = {
     # name: (corpus kind, bytes per GPU, chunk bytes, seed, strategy)
-    "text64m": ("text", 64 << 20, 1 << 20, 0x5EED0001, "Dynamic"),   # BASELINE.json configs[1]
+    "text64m": ("text", 64 << 20, 1 << 20, 0x5EED0001, "Dynamic"),   # the configuration the headline metric is quoted on
     "mixed8g": ("mixed", 8 << 30, 1 << 20, 0x5EED0004, "Dynamic"),   # configs[3] on one GPU
     "mixed1g": ("mixed", 1 << 30, 1 << 20, 0x5EED0004, "Dynamic"),   # configs[3] at 8 GPUs (1 GiB each)
     "text1g": ("text", 1 << 30, 1 << 20, 0x5EED0001, "Dynamic"),
@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--workload", default=os.environ.get("ZG_BENCH_WORKLOAD", "text64m"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--verify-large", action="store_true", help="round-trip check through system zlib above 1 GiB too")
     return ap.parse_args()
 
 
@@ -168,12 +169,16 @@ def main():
     ctx.profile(False)
 
     verified = None
-    if rank == 0 and not args.no_verify and total <= (1 << 30):
+    if rank == 0 and not args.no_verify and (total <= (1 << 30) or args.verify_large):
         import zlib as sysz
         stream = (final if world > 1 else d_out)[:out_n].cpu().numpy().tobytes()
         plain = sysz.decompress(stream)
-        ref = za.corpus(kind, total, seed=seed)
-        verified = plain == ref
+        del stream
+        verified = len(plain) == total
+        piece = 256 << 20
+        for off in range(0, total, piece):  # compare against the generator piecewise (bounded host memory)
+            m = min(piece, total - off)
+            verified = verified and plain[off:off + m] == za.corpus(kind, m, seed=seed, offset=off)
         if not verified:
             raise SystemExit("round trip through system zlib FAILED")
 

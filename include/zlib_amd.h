@@ -89,7 +89,8 @@ int zg_compress_device(zg_ctx *ctx, const void *d_in, size_t n, int strategy, co
  * (base_bit % 8) into d_out.  Byte 0 of d_out is byte base_bit/8 of the final
  * stream; when the phase is non-zero it holds only this rank's bits and must
  * be OR-ed with the previous rank's last byte.  first_rank writes the 78 01
- * header (base_bit must then be 0), last_rank sets BFINAL on its last block
+ * header in front of its blocks (base_bit must then be 16, the first bit after
+ * the header; byte 0 of d_out is then byte 0 of the stream), last_rank sets BFINAL on its last block
  * and appends the Adler-32 passed in `adler` (combined by the caller with
  * zg_adler32_combine). */
 typedef struct zg_shard_info {

@@ -1,7 +1,7 @@
 """Multi-GPU assembly of one zlib stream from per-rank runs of chunks.
 
 The input is cut into contiguous runs of whole chunks, one run per rank
-(SURVEY: chunks are independent given the 32 KiB of input before them).  The
+(a chunk's blocks depend only on its own bytes and the 32 KiB of input before them).  The
 only exchange is:
 
   1. one all_gather of three integers per rank (block bit total, Adler-32 of
