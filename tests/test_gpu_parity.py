@@ -76,6 +76,47 @@ def test_lz77_tokens_text_and_binary(za, z):
         assert comp.compress_packed(data) == z.lz77_zlib(data, fast=True), kind
 
 
+@pytest.mark.parametrize("window,min_len,max_len", [(2048, 3, 258), (4096, 4, 258), (4096, 3, 64), (8192, 6, 258),
+                                                    (20000, 3, 258), (32737, 3, 258), (32750, 4, 100),
+                                                    (32768, 5, 258), (32768, 4, 258)])
+def test_lz77_parameter_sweep(za, z, window, min_len, max_len):
+    """Windows on both sides of the index kernels' limits and every min_match_length class of the two-level
+    search (3, 4, 5 and above), against the verbatim candidate loop."""
+    comp = za.LZ77Compressor.with_window_size(window)
+    comp.min_match_length, comp.max_match_length = min_len, max_len
+    rng = random.Random(window * 7 + min_len)
+    cases = [za.corpus("text", 90_000, seed=window), za.corpus("binary", 70_000, seed=min_len),
+             bytes(rng.choice(b"abcde") for _ in range(50_000)),
+             (b"0123456789abcdef" * 40 + bytes(rng.randrange(256) for _ in range(37))) * 90]
+    for data in cases:
+        want = z.lz77_compress(data, window=window, min_len=min_len, max_len=max_len)
+        assert comp.compress_packed(data) == want, (window, min_len, max_len, data[:16])
+
+
+def test_far_members_at_the_edge_of_the_window(za, z):
+    """Chains whose links are almost a full window long, so that the entry the index kernel records lies up to
+    two windows behind the position."""
+    rng = random.Random(99)
+    marker = b"\xfe\xfdQZ#@!"
+    for gap in (32768, 32767, 32766, 32705, 32704, 30000):
+        filler = lambda n: bytes(rng.randrange(64) for _ in range(n))
+        data = b"".join(marker + filler(gap - len(marker)) for _ in range(5)) + marker + filler(100)
+        assert za.zlib_compressor().compress_packed(data) == z.lz77_zlib(data, fast=True), gap
+
+
+def test_conservative_index_kernel(za, z, monkeypatch):
+    """The index variant the library falls back to when the exchange-order check trips gives the same streams."""
+    monkeypatch.setenv("ZLIB_AMD_SAFE_INDEX", "1")
+    ctx = za.Context(0)
+    try:
+        for data in (za.corpus("text", 400_000), za.corpus("mixed", 300_000, seed=5), b"a" * 70_000):
+            got = za.compress(data, za.Strategy.Dynamic, chunk_bytes=65536, ctx=ctx)
+            assert got == za.compress(data, za.Strategy.Dynamic, chunk_bytes=65536)
+            assert got == z.compress_chunked(data, z.DYNAMIC, 65536, fast=True)
+    finally:
+        ctx.close()
+
+
 def test_huffman_tables(za, z):
     rng = random.Random(4)
     for data in [za.corpus("text", 50_000), za.corpus("binary", 30_000), b"a" * 5000, b"hello hello hello hello", b""]:

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -41,8 +42,8 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
-enum KernelId { K_INDEX, K_MATCH, K_PARSE, K_HUFFMAN, K_TILEBITS, K_OFFSETS, K_ENCODE, K_ADLER, K_STORED, K_MISC, K_COUNT };
-const char *const kKernelNames[K_COUNT] = {"k_index", "k_match", "k_parse", "k_huffman", "k_tile_bits",
+enum KernelId { K_INDEX, K_MATCH, K_MATCH_LO, K_PARSE, K_HUFFMAN, K_TILEBITS, K_OFFSETS, K_ENCODE, K_ADLER, K_STORED, K_MISC, K_COUNT };
+const char *const kKernelNames[K_COUNT] = {"k_index", "k_match", "k_match_lo", "k_parse", "k_huffman", "k_tile_bits",
                                            "k_offsets", "k_encode", "k_adler", "k_stored", "misc"};
 
 // device scalars
@@ -61,7 +62,7 @@ struct zg_ctx {
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::string err;
-    DevBuf far, next, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
+    DevBuf far, next, far3, next3, open_list, open_cnt, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
         scalars, stage_in, stage_out, misc, flag, sub_exit, sub_exit2, merged, tile_cnt, adler_blk;
     // shard state kept between zg_shard_begin and zg_shard_finish
     bool shard_active = false;
@@ -197,19 +198,40 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
               int64_t final_chunk, bool want_codes) {
     const uint64_t bs = g.first + (uint64_t)c0 * g.chunk_bytes;
     const uint64_t be = std::min<uint64_t>(g.end, g.first + (uint64_t)c1 * g.chunk_bytes);
-    const uint64_t ib0 = (bs > mp.window ? bs - mp.window : 0) & ~(uint64_t)15;  // scratch arrays start here
+    const uint64_t back = index_lookback(mp.window);
+    const uint64_t ib0 = (bs > back ? bs - back : 0) & ~(uint64_t)15;  // scratch arrays start here
     const uint64_t span = be - ib0;
+    const bool two_level = mp.min_len < 5;  // lengths 3 and 4 need the three-byte chains
+    const uint32_t rec_min = mp.min_len < 5 ? 5u : mp.min_len;
     HIPCHK(c->far.ensure(span * 2 + 64));
     HIPCHK(c->next.ensure(span * 2 + 64));
+    if (two_level) {
+        HIPCHK(c->far3.ensure(span * 2 + 64));
+        HIPCHK(c->next3.ensure(span * 2 + 64));
+    }
     HIPCHK(c->match.ensure(span * 4 + 64));
     HIPCHK(c->tokens.ensure((be - bs) * 4 + 64));
     if (span) {
+        uint32_t *status = &c->scalars.as<Scalars>()->status;
         LAUNCH(K_MISC, hipMemsetAsync(c->next.p, 0, span * 2, c->stream));
-        LAUNCH(K_INDEX, launch_index(g.data, g.end, ib0, be, bs, mp.window, c->far.as<uint16_t>(),
-                                     c->next.as<uint16_t>(), ib0, &c->scalars.as<Scalars>()->status, c->index_safe,
-                                     c->stream));
-        LAUNCH(K_MATCH, launch_match(g, c0, c1, mp, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
-                                     c->match.as<uint32_t>(), c->stream));
+        LAUNCH(K_INDEX, launch_index(g.data, g.end, ib0, be, bs, mp.window, 5, c->far.as<uint16_t>(),
+                                     c->next.as<uint16_t>(), ib0, status, c->index_safe, c->stream));
+        if (two_level) {
+            const uint64_t ntiles = (uint64_t)(c1 - c0) * match_tiles_per_chunk(g.chunk_bytes);
+            HIPCHK(c->open_list.ensure(ntiles * kMatchTile * sizeof(uint2)));
+            HIPCHK(c->open_cnt.ensure(ntiles * sizeof(uint32_t)));
+            LAUNCH(K_MISC, hipMemsetAsync(c->next3.p, 0, span * 2, c->stream));
+            LAUNCH(K_INDEX, launch_index(g.data, g.end, ib0, be, bs, mp.window, 3, c->far3.as<uint16_t>(),
+                                         c->next3.as<uint16_t>(), ib0, status, c->index_safe, c->stream));
+            LAUNCH(K_MATCH, launch_match(g, c0, c1, mp, rec_min, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
+                                         c->match.as<uint32_t>(), c->far3.as<uint16_t>(), c->open_list.as<uint2>(),
+                                         c->open_cnt.as<uint32_t>(), c->stream));
+            LAUNCH(K_MATCH_LO, launch_match_lo(g, c0, c1, mp, c->next3.as<uint16_t>(), ib0, c->match.as<uint32_t>(),
+                                               c->open_list.as<uint2>(), c->open_cnt.as<uint32_t>(), c->stream));
+        } else {
+            LAUNCH(K_MATCH, launch_match(g, c0, c1, mp, rec_min, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
+                                         c->match.as<uint32_t>(), nullptr, nullptr, nullptr, c->stream));
+        }
     }
     {
         const uint64_t nc = c1 - c0;
@@ -382,6 +404,7 @@ int zg_init(int device, zg_ctx **ctx) {
     zg_ctx *c = new (std::nothrow) zg_ctx();
     if (!c) return ZG_ERR_NOMEM;
     c->device = device;
+    if (const char *e = std::getenv("ZLIB_AMD_SAFE_INDEX")) c->index_safe = e[0] == '1';  // test hook
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return ZG_ERR_NO_DEVICE;
@@ -395,7 +418,7 @@ void zg_destroy(zg_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf *bufs[] = {&c->far, &c->next, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
+    DevBuf *bufs[] = {&c->far, &c->next, &c->far3, &c->next3, &c->open_list, &c->open_cnt, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
                       &c->block_bits, &c->bit_off, &c->tile_bits, &c->adler_part, &c->scalars, &c->stage_in,
                       &c->stage_out, &c->misc, &c->flag, &c->sub_exit, &c->sub_exit2, &c->merged, &c->tile_cnt,
                       &c->adler_blk};

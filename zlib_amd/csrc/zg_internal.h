@@ -30,6 +30,9 @@ constexpr uint32_t kMatchThreads = 1024;
 constexpr uint32_t kParseSub = 1024;   // positions per speculative parse sub-tile (> kMaxMatch)
 constexpr uint32_t kEmitTile = 4096;   // positions per unit-emission workgroup
 constexpr uint32_t kEmitThreads = 256;
+inline uint32_t match_tiles_per_chunk(uint64_t chunk_bytes) {
+    return (uint32_t)((chunk_bytes + kMatchTile - 1) / kMatchTile);
+}
 inline uint32_t parse_subs_per_chunk(uint64_t chunk_bytes) {
     return (uint32_t)((chunk_bytes + kParseSub - 1) / kParseSub);
 }
@@ -59,11 +62,24 @@ struct ChunkGrid {
 };
 
 // launchers (each enqueues on `s` and returns the HIP status of the launch)
+// index of positions [r0, r1) by the hash of their first key_bytes (3 or 5) bytes; far[] for [far_lo, r1) only.
+// The arrays start at view position `base`, which must lie index_lookback(window) or more behind far_lo
+// (or at 0), and next[] must be zero on entry.
 hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
-                        uint32_t window, uint16_t *far, uint16_t *next, uint64_t base, uint32_t *status, bool safe,
-                        hipStream_t s);
-hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *far,
-                        const uint16_t *next, uint64_t base, uint32_t *match, hipStream_t s);
+                        uint32_t window, int key_bytes, uint16_t *far, uint16_t *next, uint64_t base,
+                        uint32_t *status, bool safe, hipStream_t s);
+uint64_t index_lookback(uint32_t window);
+// level 1: lengths >= rec_min along the five-byte chains.  With far_lo (the far[] of the three-byte index)
+// it also lists, per tile, the positions it leaves without a length and that have three-byte candidates:
+// open_list[tile * kMatchTile + i] = (tile position | distance of a search-ending candidate << 16, far_lo),
+// open_cnt[tile] entries.
+hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, uint32_t rec_min,
+                        const uint16_t *far, const uint16_t *next, uint64_t base, uint32_t *match,
+                        const uint16_t *far_lo, uint2 *open_list, uint32_t *open_cnt, hipStream_t s);
+// level 2: lengths 3 and 4 along the three-byte chains, for the listed positions
+hipError_t launch_match_lo(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *next,
+                           uint64_t base, uint32_t *match, const uint2 *open_list, const uint32_t *open_cnt,
+                           hipStream_t s);
 hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint32_t *match, uint64_t base,
                         uint8_t *flag, uint64_t flag_bytes, uint32_t *sub_exit, uint32_t *sub_exit2, uint8_t *merged,
                         uint32_t *tile_cnt, uint32_t *tokens, uint64_t tok_base, uint32_t *ntok, uint32_t *freq,

@@ -1,7 +1,7 @@
-// LZ77 match finding for gfx950: a forward-chain 3-gram index (k_index) and an
-// exhaustive, position-parallel longest-match search over LDS-staged windows
-// (k_match).  Together they reproduce, for EVERY position of a chunk, the
-// result of the candidate loop of LZ77Compressor::compress
+// LZ77 match finding for gfx950: forward-chain K-gram indexes (K = 5 and K = 3)
+// and an exhaustive, position-parallel longest-match search over LDS-staged
+// windows, in two levels.  Together they reproduce, for EVERY position of a
+// chunk, the result of the candidate loop of LZ77Compressor::compress
 // (reference src/lz77.rs:156-190):
 //
 //   candidates s run upward from max(0, pos - window) while s + min_len < pos;
@@ -12,28 +12,103 @@
 //   otherwise it is recorded iff M >= min_len and M > best (strict: ties keep
 //          the farthest candidate).
 //
-// Only positions sharing the first three bytes can reach M >= min_len (>= 3),
-// so walking the per-hash forward chain from the farthest in-window member
-// visits every relevant candidate in the reference's order.
+// Level 1 (k_match) walks the chain of positions sharing the hash of the first
+// FIVE bytes: it sees every candidate with M >= 5 in the reference's order, so
+// it settles every position whose answer is five bytes or longer, and finds the
+// search-ending candidate T if that one is five bytes or longer.  A search-ending
+// candidate shorter than that sits at distance 4 or 5 and cannot precede a
+// recorded candidate of five bytes or more (those lie at distance >= 7), so
+// level 1 never needs it.
+// Level 2 (k_match_lo, only when min_len <= 4) takes the positions level 1 left
+// open.  All their candidates below T match fewer than five bytes, so the
+// answer is the farthest candidate with four common bytes, else the farthest
+// with three: a walk along the THREE-byte chain that stops at the first
+// four-byte agreement.
 #include "zg_internal.h"
+
+#include <type_traits>
 
 #ifndef ZG_MATCH_STEPS
 #define ZG_MATCH_STEPS 8
+#endif
+#ifndef ZG_LO_STEPS
+#define ZG_LO_STEPS 8
 #endif
 
 namespace zg {
 
 // ---------------------------------------------------------------------------
-// k_index: one wave per segment walks positions in batches of 64, keeping per
-// hash bucket the newest member (head) and the farthest in-window member
-// (tail), plus a 64 Ki-entry ring of forward links.  Outputs, per position p:
+// Index.  Outputs, per position p (members of a bucket = positions whose first
+// K bytes hash alike):
 //   far[p]  = p - (smallest bucket member >= p - window), 0 if none
 //   next[s] = distance from s to the next bucket member, 0 if none within window
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t hash3(uint32_t tri) { return (tri * 0x9E3779B1u) >> (32 - kIdxHashBits); }
 
+template <int K>
+__device__ __forceinline__ uint32_t key_hash(uint32_t lo, uint32_t hi);
+template <>
+__device__ __forceinline__ uint32_t key_hash<3>(uint32_t lo, uint32_t) {
+    return hash3(lo & 0x00FFFFFFu);
+}
+template <>
+__device__ __forceinline__ uint32_t key_hash<5>(uint32_t lo, uint32_t hi) {
+    return (lo * 0x9E3779B1u + (hi & 0xFFu) * 0x85EBCA6Bu) >> (32 - kIdxHashBits);
+}
+
+// the first K bytes at view position p (p + K <= n_view): low four in lo, the fifth in hi
+template <int K>
+__device__ __forceinline__ void load_key(const uint8_t *__restrict__ data, uint64_t p, uint64_t n_view, uint32_t &lo,
+                                         uint32_t &hi) {
+    if (p + 4 <= n_view) {
+        __builtin_memcpy(&lo, data + p, 4);  // one unaligned dword load
+    } else {
+        lo = (uint32_t)data[p] | ((uint32_t)data[p + 1] << 8) | ((uint32_t)data[p + 2] << 16);
+    }
+    hi = (K > 4) ? (uint32_t)data[p + 4] : 0u;
+}
+
+// The same without branches, so that the loads can stay in flight across loop iterations: the address is
+// clamped into the view (n_view >= 8) and the bytes are shifted into place afterwards.  The result is
+// meaningful only when p + K <= n_view.
+template <int K>
+struct RawKey {
+    uint32_t a, b;
+};
+template <int K>
+__device__ __forceinline__ RawKey<K> raw_load(const uint8_t *__restrict__ data, uint64_t p, uint64_t n_view) {
+    const uint64_t last = n_view - (K > 4 ? 8 : 4);
+    const uint64_t pc = p < last ? p : last;
+    RawKey<K> r;
+    __builtin_memcpy(&r.a, data + pc, 4);
+    r.b = 0;
+    if (K > 4) __builtin_memcpy(&r.b, data + pc + 4, 4);
+    return r;
+}
+template <int K>
+__device__ __forceinline__ uint32_t raw_hash(RawKey<K> r, uint64_t p, uint64_t n_view) {
+    const uint64_t last = n_view - (K > 4 ? 8 : 4);
+    const uint32_t sh = p < last ? 0u : ((uint32_t)(p - last) & 7u) * 8u;
+    if (K > 4) {
+        const uint64_t v = (((uint64_t)r.b << 32) | r.a) >> sh;
+        return key_hash<K>((uint32_t)v, (uint32_t)(v >> 32));
+    }
+    return key_hash<K>(r.a >> (sh & 31u), 0u);
+}
+
+template <int K>
+__device__ __forceinline__ uint32_t hash_at(const uint8_t *__restrict__ data, uint64_t p, uint64_t n_view) {
+    uint32_t lo, hi;
+    load_key<K>(data, p, n_view, lo, hi);
+    return key_hash<K>(lo, hi);
+}
+
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
+// k_index: the conservative variant.  One wave per segment walks positions in batches of 64, keeping per
+// bucket the newest member (head) and the farthest in-window member (tail), plus a 64 Ki-entry ring of forward
+// links; lanes of a batch that share a bucket are grouped with ballots.
+template <int K>
 __global__ __launch_bounds__(64) void k_index(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
                                                uint64_t r1, uint64_t far_lo, uint32_t window,
                                                uint16_t *__restrict__ far, uint16_t *__restrict__ next,
@@ -58,12 +133,8 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t *__restrict__ data, 
         const uint32_t q = qb + lane;
         const uint64_t p = a0 + q;
         const bool inseg = q < q_end;
-        const bool valid = inseg && (p + 3 <= n_view);
-        uint32_t h = 0;
-        if (valid) {
-            uint32_t tri = (uint32_t)data[p] | ((uint32_t)data[p + 1] << 8) | ((uint32_t)data[p + 2] << 16);
-            h = hash3(tri);
-        }
+        const bool valid = inseg && (p + K <= n_view);
+        const uint32_t h = valid ? hash_at<K>(data, p, n_view) : 0u;
         // lanes of this batch that share my bucket
         uint64_t mygrp = 0;
         uint64_t todo = __ballot(valid);
@@ -118,202 +189,215 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t *__restrict__ data, 
     }
 }
 
-// k_index_x: the same index, with the per-batch grouping done by the LDS itself and sixteen waves per segment.
-// One ds_wrxchg on the bucket head hands every lane the bucket member inserted just before it, including
-// lanes of the same batch, PROVIDED the LDS serialises same-address lanes of one instruction in ascending lane
-// order.  gfx950 does (probed over 6.5*10^8 colliding exchanges, tools/probe/probe_exch.hip); the kernel still
-// checks every returned value (a member handed out of order is >= the lane's own position) and raises bit 1 of
-// *status, upon which the host redoes the call with k_index.
-// The waves of a workgroup share the tables but own disjoint hash buckets (bucket & 15 == wave), hence also
-// disjoint ring slots, so they never synchronise: each wave scans all positions of the segment, gathers the
-// next (up to) 64 positions of its own buckets into a small staging area, and inserts them as one batch.
-#ifndef ZG_IDX_WAVES
-#define ZG_IDX_WAVES 8
+// k_index_d: the fast variant, one wave per segment, three small LDS tables and no walking.
+//   head[h]  newest member so far.  One ds_wrxchg on it hands every lane the member inserted just before
+//            it, lanes of the same batch included, PROVIDED the LDS serialises same-address lanes of one
+//            instruction in ascending lane order.  gfx950 does (probed over 6.5*10^8 colliding exchanges,
+//            tools/probe/probe_exch.hip); the kernel still checks every returned value (a member handed out
+//            of order is not below the lane's own position) and raises bit 1 of *status, upon which the
+//            host redoes the call with k_index.
+//   old[h]   newest member among positions at least window + 1 behind the current batch: the same
+//            positions, inserted a second time with a lag of window + 64 * kIdxGroup.
+//   start[h] newest member that has no predecessor within the window (a chain start).
+// For position q: if old[h] is at or after start[h], the chain runs unbroken from old[h] up to q, so the
+// farthest in-window member is reached from old[h] by following forward links (one, or a few when the
+// batch lag leaves members between old[h] and the window's edge); otherwise the chain restarts at
+// start[h], which then is the farthest member itself.  The kernel stores that entry distance (possibly
+// beyond the window, clipped at 65535) in far[]; k_far_fix follows the links afterwards.
+// The warm-up before a segment is 2 * window + 64 * kIdxGroup positions: enough for every old[] entry that
+// can matter.
+constexpr uint32_t kIdxSegD = 128 * 1024;  // positions owned by one k_index_d workgroup
+#ifndef ZG_IDX_GROUP
+#define ZG_IDX_GROUP 4
 #endif
-constexpr uint32_t kIdxWaves = ZG_IDX_WAVES;
-constexpr uint32_t kIdxSyncEvery = 8192;  // positions between two tail sweeps / wave barriers
+constexpr uint32_t kIdxGroup = ZG_IDX_GROUP;        // batches of 64 positions handled together
+constexpr uint32_t kIdxLagPad = 64 * kIdxGroup;
 
-__global__ __launch_bounds__(64 * kIdxWaves) void k_index_x(const uint8_t *__restrict__ data, uint64_t n_view,
-                                                             uint64_t r0, uint64_t r1, uint64_t far_lo,
-                                                             uint32_t window, uint16_t *__restrict__ far,
-                                                             uint16_t *__restrict__ next, uint64_t base,
-                                                             uint32_t *status) {
-    __shared__ uint32_t s_head[kIdxBuckets];
-    __shared__ uint16_t s_tail[kIdxBuckets];
-    __shared__ uint16_t s_ring[65536];
-    __shared__ uint32_t s_stq[kIdxWaves][64];
-    __shared__ uint16_t s_sth[kIdxWaves][64];
+template <int K>
+__global__ __launch_bounds__(64) void k_index_d(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
+                                                 uint64_t r1, uint64_t far_lo, uint32_t window,
+                                                 uint16_t *__restrict__ far, uint16_t *__restrict__ next,
+                                                 uint64_t base, uint32_t *status) {
+    __shared__ uint32_t s_head[kIdxBuckets];   // position + 1, 0 = empty (all three)
+    __shared__ uint32_t s_old[kIdxBuckets];
+    __shared__ uint32_t s_start[kIdxBuckets];
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t a = r0 + (uint64_t)blockIdx.x * kIdxSegment;
-    const uint64_t b = (a + kIdxSegment < r1) ? a + kIdxSegment : r1;
-    const uint64_t a0 = a > window ? a - window : 0;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t a = r0 + (uint64_t)blockIdx.x * kIdxSegD;
     if (a >= r1) return;
+    const uint64_t b = (a + kIdxSegD < r1) ? a + kIdxSegD : r1;
+    const uint32_t lag = window + kIdxLagPad;
+    const uint64_t warm = 2ull * window + kIdxLagPad;
+    const uint64_t a0 = a > warm ? a - warm : 0;
 
-    for (uint32_t i = tid; i < kIdxBuckets; i += 64 * kIdxWaves) s_head[i] = 0;
-    for (uint32_t i = tid; i < 65536 / 2; i += 64 * kIdxWaves) reinterpret_cast<uint32_t *>(s_ring)[i] = 0;
+    for (uint32_t i = lane; i < kIdxBuckets; i += 64) {
+        s_head[i] = 0;
+        s_old[i] = 0;
+        s_start[i] = 0;
+    }
     __syncthreads();
 
+    // everything below is relative to a0 and fits 32 bits
     const uint32_t q_end = (uint32_t)(b - a0);
     const uint32_t q_main = (uint32_t)(a - a0);
+    const uint32_t q_far = far_lo > a ? (uint32_t)(far_lo - a0) : q_main;   // first position whose far[] is stored
+    const uint32_t base_rel = base > a0 ? (uint32_t)(base - a0) : 0u;       // links below it have no slot
+    const uint64_t room = n_view - a0;
+    const uint32_t n_rel = room < 0x7FFFFFFFull ? (uint32_t)room : 0x7FFFFFFFu;  // bytes from a0 to the view's end
+    const uint32_t last = n_rel - (K > 4 ? 8u : 4u);  // last offset a key load may start at (n_view >= 64)
+    const uint8_t *dseg = data + a0;
+    uint16_t *far_seg = far + ((int64_t)a0 - (int64_t)base);
+    uint16_t *next_seg = next + ((int64_t)a0 - (int64_t)base);
     bool violated = false;
 
-    // inserts the first `cnt` staged positions of this wave (ascending, all in buckets this wave owns)
-    auto insert_batch = [&](uint32_t cnt) {
-        const bool valid = lane < cnt;
-        const uint32_t q = valid ? s_stq[wave][lane] : 0u;
-        const uint32_t h = valid ? (uint32_t)s_sth[wave][lane] : 0u;
-        uint32_t t16 = 0, head1 = 0, old1 = 0;
-        if (valid) {
-            t16 = s_tail[h];    // tail and head as the previous batches left them
-            head1 = s_head[h];
-            old1 = atomicExch(&s_head[h], q + 1u);  // member inserted just before me (+1), batch mates included
-            violated |= (old1 != 0u && old1 - 1u >= q);
+    auto raw_at = [&](uint32_t q) -> RawKey<K> {  // branch-free: the offset is clamped into the view
+        const uint32_t qc = q < last ? q : last;
+        RawKey<K> r;
+        __builtin_memcpy(&r.a, dseg + qc, 4);
+        r.b = 0;
+        if (K > 4) __builtin_memcpy(&r.b, dseg + qc + 4, 4);
+        return r;
+    };
+    auto hash_of = [&](RawKey<K> r, uint32_t q, bool exact) -> uint32_t {
+        if (exact) return key_hash<K>(r.a, r.b);  // the load was not clamped
+        const uint32_t sh = q > last ? ((q - last) & 7u) * 8u : 0u;
+        if (K > 4) {
+            const uint64_t v = (((uint64_t)r.b << 32) | r.a) >> sh;
+            return key_hash<K>((uint32_t)v, (uint32_t)(v >> 32));
         }
-        const uint32_t hq = head1 - 1u;
-        const bool first_of_group = valid && old1 == head1;
-        const bool has_old = valid && head1 != 0u && (q - hq) <= window;
-        uint32_t pp = kNone;
-        if (valid && !first_of_group)
-            pp = old1 - 1u;
-        else if (has_old)
-            pp = hq;
-        // the first lane of every bucket group publishes itself; the group's last lane rewrites the tail below
-        if (first_of_group) s_tail[h] = (uint16_t)(q & 0xFFFFu);
-        if (valid) s_ring[q & 0xFFFFu] = 0;
-        if (valid && pp != kNone) s_ring[pp & 0xFFFFu] = (uint16_t)(q - pp);
-        uint32_t f = kNone;
-        bool is_last = false;
-        if (valid) {
-            if (has_old) {
-                uint32_t t = hq - ((hq - t16) & 0xFFFFu);
-                const uint32_t lo = q > window ? q - window : 0u;
-                for (int guard = 0; t < lo && guard < 65536; ++guard) {  // may run on into this batch's links
-                    const uint32_t dl = s_ring[t & 0xFFFFu];
-                    if (dl == 0) break;
-                    t += dl;
-                }
-                f = t;
-            } else if (!first_of_group) {
-                const uint32_t gf = s_tail[h];  // the group's first lane, a few hundred positions back at most
-                f = q - ((q - gf) & 0xFFFFu);
-            }
-            is_last = s_head[h] == q + 1u;
-        }
-        if (valid && is_last) s_tail[h] = (uint16_t)((f != kNone ? f : q) & 0xFFFFu);
-        if (valid && q >= q_main) {
-            const uint64_t p = a0 + q;
-            if (pp != kNone && a0 + pp >= base) next[(a0 + pp) - base] = (uint16_t)(q - pp);
-            if (p >= far_lo) far[p - base] = (f != kNone) ? (uint16_t)(q - f) : (uint16_t)0;
-        }
+        return key_hash<K>(r.a >> (sh & 31u), 0u);
     };
 
-    auto load_tri = [&](uint32_t q) -> uint32_t {  // three bytes at segment position q, ~0 if none
-        const uint64_t p = a0 + q;
-        if (q < q_end && p + 4 <= n_view) {
-            uint32_t v;
-            __builtin_memcpy(&v, data + p, 4);  // one unaligned dword load
-            return v & 0x00FFFFFFu;
+    // Positions are taken in groups of kIdxGroup batches.  The three steps of a group (insert the lagging
+    // positions and exchange the heads; mark chain starts; read old[] and start[]) are issued for all its
+    // batches back to back, so that the wave waits for the LDS twice per group instead of twice per batch.
+    // Within a group this is safe: the lag keeps every old[] entry behind the window of every lane of the
+    // group, and a chain start cannot share its bucket with a lane less than a window before it.
+    RawKey<K> cur_m[kIdxGroup], cur_r[kIdxGroup], nxt_m[kIdxGroup], nxt_r[kIdxGroup];
+    auto group = [&](uint32_t qg, auto full_c) {
+        constexpr bool full = decltype(full_c)::value;  // every lane of the group is a position with K bytes
+#pragma unroll
+        for (int k = 0; k < (int)kIdxGroup; k++) {
+            const uint32_t q = qg + (kIdxGroup + (uint32_t)k) * 64 + lane;
+            nxt_m[k] = raw_at(q);
+            nxt_r[k] = raw_at(q >= lag ? q - lag : 0u);
         }
-        if (q < q_end && p + 3 <= n_view)
-            return (uint32_t)data[p] | ((uint32_t)data[p + 1] << 8) | ((uint32_t)data[p + 2] << 16);
-        return 0xFFFFFFFFu;
+        uint32_t h[kIdxGroup], old1[kIdxGroup];
+        bool valid[kIdxGroup];
+#pragma unroll
+        for (int k = 0; k < (int)kIdxGroup; k++) {
+            const uint32_t q = qg + (uint32_t)k * 64 + lane;
+            valid[k] = full || (q < q_end && q + K <= n_rel);
+            h[k] = hash_of(cur_m[k], q, full);
+            const uint32_t hr = hash_of(cur_r[k], q - lag, true);  // a lagging position is never near the end
+            if (q >= lag) atomicMax(&s_old[hr], q - lag + 1u);
+        }
+#pragma unroll
+        for (int k = 0; k < (int)kIdxGroup; k++) {
+            const uint32_t q = qg + (uint32_t)k * 64 + lane;
+            old1[k] = 0;
+            if (valid[k]) old1[k] = atomicExch(&s_head[h[k]], q + 1u);  // member inserted just before me (+1)
+        }
+        bool linked[kIdxGroup];
+#pragma unroll
+        for (int k = 0; k < (int)kIdxGroup; k++) {
+            const uint32_t q = qg + (uint32_t)k * 64 + lane;
+            violated |= old1[k] > q;
+            linked[k] = old1[k] != 0u && (q + 1u - old1[k]) <= window;
+            if (valid[k] && !linked[k]) atomicMax(&s_start[h[k]], q + 1u);
+        }
+        __builtin_amdgcn_wave_barrier();  // the LDS runs one wave's accesses in program order
+        uint32_t e1[kIdxGroup], c1[kIdxGroup];
+#pragma unroll
+        for (int k = 0; k < (int)kIdxGroup; k++) {
+            e1[k] = s_old[h[k]];
+            c1[k] = s_start[h[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < (int)kIdxGroup; k++) {
+            const uint32_t q = qg + (uint32_t)k * 64 + lane;
+            uint32_t dist = 0;
+            if (valid[k]) {
+                dist = (e1[k] != 0u && e1[k] >= c1[k]) ? q + 1u - e1[k] : q + 1u - c1[k];
+                if (q >= q_main && linked[k] && old1[k] > base_rel) next_seg[old1[k] - 1u] = (uint16_t)(q + 1u - old1[k]);
+            }
+            if ((full || q < q_end) && q >= q_far) far_seg[q] = (uint16_t)(dist < 65535u ? dist : 65535u);
+        }
+#pragma unroll
+        for (int k = 0; k < (int)kIdxGroup; k++) {
+            cur_m[k] = nxt_m[k];
+            cur_r[k] = nxt_r[k];
+        }
     };
-    uint32_t count = 0;    // staged positions (wave uniform)
-    uint32_t first_q = 0;  // segment position of the first staged one
-    const uint32_t span_limit = window - 64;  // batch mates must lie within each other's window (window >= 2048 here)
-    constexpr int kAhead = 8;  // raw batches whose bytes are in flight
-    uint32_t tri_cur[kAhead], tri_nxt[kAhead];
 #pragma unroll
-    for (int k = 0; k < kAhead; k++) tri_cur[k] = load_tri((uint32_t)k * 64 + lane);
-    for (uint32_t qg = 0; qg < q_end; qg += 64 * kAhead) {
-        if (qg != 0 && (qg & (kIdxSyncEvery - 1)) == 0) {
-            // Ring slots are shared by positions 65536 apart, which different waves may own.  Keeping every
-            // bucket's tail within window + kIdxSyncEvery of the scan point, and the waves within kIdxSyncEvery
-            // of each other, keeps a slot's old owner done with it before the new owner writes it
-            // (window + 2 * kIdxSyncEvery + span of a staged batch < 65536).
-            if (count) {
-                insert_batch(count);
-                count = 0;
-            }
-            __syncthreads();
-            for (uint32_t k = 0; k < kIdxBuckets / (64 * kIdxWaves); k++) {  // this wave's buckets
-                const uint32_t hb = ((k * 64 + lane) * kIdxWaves) | wave;
-                const uint32_t head1 = s_head[hb];
-                if (head1 != 0u) {
-                    const uint32_t hq = head1 - 1u;
-                    const uint32_t lo = qg > window ? qg - window : 0u;
-                    if (hq < lo) {
-                        s_head[hb] = 0;  // every member has left the window
-                    } else {
-                        uint32_t t = hq - ((hq - (uint32_t)s_tail[hb]) & 0xFFFFu);
-                        for (int guard = 0; t < lo && guard < 65536; ++guard) {
-                            const uint32_t dl = s_ring[t & 0xFFFFu];
-                            if (dl == 0) break;
-                            t += dl;
-                        }
-                        s_tail[hb] = (uint16_t)(t & 0xFFFFu);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int k = 0; k < kAhead; k++) tri_nxt[k] = load_tri(qg + (uint32_t)(kAhead + k) * 64 + lane);
-#pragma unroll
-        for (int k = 0; k < kAhead; k++) {
-            const uint32_t qb = qg + (uint32_t)k * 64;
-            const uint32_t q = qb + lane;
-            const uint32_t tri = tri_cur[k];
-            const bool valid = tri != 0xFFFFFFFFu;
-            const uint32_t h = valid ? hash3(tri) : 0u;
-            const bool mine = valid && (h & (kIdxWaves - 1)) == wave;
-            const uint64_t mask = __ballot(mine);
-            const uint32_t n = (uint32_t)__popcll(mask);
-            if (count != 0 && (count + n > 64 || qb + 63 - first_q > span_limit)) {
-                insert_batch(count);
-                count = 0;
-            }
-            if (count == 0 && n != 0) first_q = qb + (uint32_t)(__ffsll((unsigned long long)mask) - 1);
-            if (mine) {
-                const uint32_t slot = count + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                s_stq[wave][slot] = q;
-                s_sth[wave][slot] = (uint16_t)h;
-            }
-            count += n;
-        }
-#pragma unroll
-        for (int k = 0; k < kAhead; k++) tri_cur[k] = tri_nxt[k];
+    for (int k = 0; k < (int)kIdxGroup; k++) {
+        const uint32_t q = (uint32_t)k * 64 + lane;
+        cur_m[k] = raw_at(q);
+        cur_r[k] = raw_at(0u);
     }
-    if (count) insert_batch(count);
-    // positions of the owned range that were never inserted (no three bytes left) have no far candidate
-    for (uint64_t p = (a > far_lo ? a : far_lo) + tid; p < b; p += 64 * kIdxWaves)
-        if (p + 3 > n_view) far[p - base] = 0;
+    constexpr uint32_t kSpan = 64 * kIdxGroup;
+    for (uint32_t qg = 0; qg < q_end; qg += kSpan) {
+        if (qg + kSpan <= q_end && qg + kSpan + 8u <= n_rel)
+            group(qg, std::true_type{});
+        else
+            group(qg, std::false_type{});
+    }
     if (__any(violated) && lane == 0) atomicOr(status, 2u);
+}
+
+// k_far_fix: turns the entry distances k_index_d left in far[] into distances of the farthest in-window member.
+template <int K>
+__global__ __launch_bounds__(256) void k_far_fix(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t far_lo,
+                                                  uint64_t r1, uint32_t window, uint16_t *__restrict__ far,
+                                                  const uint16_t *__restrict__ next, uint64_t base) {
+    const uint64_t p = far_lo + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= r1) return;
+    uint32_t d = far[p - base];
+    if (d <= window) return;
+    const uint32_t d_max = 2u * window + kIdxLagPad - 1u;
+    if (d == 65535u && d_max > 65535u) {
+        // clipped: the entry is the nearest bucket member at distance 65535 or more (no member lies between
+        // it and that distance, or the index would have chosen that one)
+        const uint32_t hp = hash_at<K>(data, p, n_view);
+        uint32_t e = 0;
+        for (uint32_t t = 65535u; t <= d_max && (uint64_t)t <= p; t++)
+            if (hash_at<K>(data, p - t, n_view) == hp) {
+                e = t;
+                break;
+            }
+        d = e;
+    }
+    for (int guard = 0; d > window && guard < 4096; ++guard) {
+        if (p - d < base) {  // cannot happen while the scratch arrays reach index_lookback() behind far_lo
+            d = 0;
+            break;
+        }
+        const uint32_t nx = next[(p - d) - base];
+        d = nx ? d - nx : 0u;  // a missing link cannot occur on an unbroken chain; treat it as "no candidate"
+    }
+    far[p - base] = (uint16_t)(d <= window ? d : 0u);
 }
 
 // k_index_brute: the same two arrays for small windows (LZ77Compressor's default is 144), one thread per
 // position, by direct scan of the window on either side.
+template <int K>
 __global__ __launch_bounds__(256) void k_index_brute(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
                                                       uint64_t r1, uint64_t far_lo, uint32_t window,
                                                       uint16_t *__restrict__ far, uint16_t *__restrict__ next,
                                                       uint64_t base) {
     const uint64_t p = r0 + (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= r1) return;
-    auto hash_at = [&](uint64_t x) -> uint32_t {
-        return hash3((uint32_t)data[x] | ((uint32_t)data[x + 1] << 8) | ((uint32_t)data[x + 2] << 16));
-    };
     uint32_t fd = 0, nd = 0;
-    if (p + 3 <= n_view) {
-        const uint32_t h = hash_at(p);
+    if (p + K <= n_view) {
+        const uint32_t h = hash_at<K>(data, p, n_view);
         const uint64_t lo = p > window ? p - window : 0;
         for (uint64_t s = lo; s < p; s++)
-            if (hash_at(s) == h) {
+            if (hash_at<K>(data, s, n_view) == h) {
                 fd = (uint32_t)(p - s);
                 break;
             }
-        for (uint64_t q = p + 1; q <= p + window && q + 3 <= n_view; q++)
-            if (hash_at(q) == h) {
+        for (uint64_t q = p + 1; q <= p + window && q + K <= n_view; q++)
+            if (hash_at<K>(data, q, n_view) == h) {
                 nd = (uint32_t)(q - p);
                 break;
             }
@@ -322,27 +406,45 @@ __global__ __launch_bounds__(256) void k_index_brute(const uint8_t *__restrict__
     if (p >= far_lo) far[p - base] = (uint16_t)fd;
 }
 
-hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
-                        uint32_t window, uint16_t *far, uint16_t *next, uint64_t base, uint32_t *status, bool safe,
-                        hipStream_t s) {
-    if (r1 <= r0) return hipSuccess;
-    const uint64_t nseg = (r1 - r0 + kIdxSegment - 1) / kIdxSegment;
-    if (window < 2048)
-        hipLaunchKernelGGL(k_index_brute, dim3((uint32_t)((r1 - r0 + 255) / 256)), dim3(256), 0, s, data, n_view, r0,
-                           r1, far_lo, window, far, next, base);
-    else if (safe)
-        hipLaunchKernelGGL(k_index, dim3((uint32_t)nseg), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, far,
+template <int K>
+static hipError_t launch_index_k(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
+                                 uint32_t window, uint16_t *far, uint16_t *next, uint64_t base, uint32_t *status,
+                                 bool safe, hipStream_t s) {
+    if (window < 2048 || n_view < 64) {
+        hipLaunchKernelGGL(k_index_brute<K>, dim3((uint32_t)((r1 - r0 + 255) / 256)), dim3(256), 0, s, data, n_view,
+                           r0, r1, far_lo, window, far, next, base);
+    } else if (safe) {
+        const uint64_t nseg = (r1 - r0 + kIdxSegment - 1) / kIdxSegment;
+        hipLaunchKernelGGL(k_index<K>, dim3((uint32_t)nseg), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, far,
                            next, base);
-    else
-        hipLaunchKernelGGL(k_index_x, dim3((uint32_t)nseg), dim3(64 * kIdxWaves), 0, s, data, n_view, r0, r1, far_lo,
-                           window, far, next, base, status);
+    } else {
+        const uint64_t nseg = (r1 - r0 + kIdxSegD - 1) / kIdxSegD;
+        hipLaunchKernelGGL(k_index_d<K>, dim3((uint32_t)nseg), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window,
+                           far, next, base, status);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (r1 > far_lo)
+            hipLaunchKernelGGL(k_far_fix<K>, dim3((uint32_t)((r1 - far_lo + 255) / 256)), dim3(256), 0, s, data, n_view,
+                               far_lo, r1, window, far, next, base);
+    }
     return hipGetLastError();
 }
 
+hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
+                        uint32_t window, int key_bytes, uint16_t *far, uint16_t *next, uint64_t base,
+                        uint32_t *status, bool safe, hipStream_t s) {
+    if (r1 <= r0) return hipSuccess;
+    if (key_bytes == 5)
+        return launch_index_k<5>(data, n_view, r0, r1, far_lo, window, far, next, base, status, safe, s);
+    return launch_index_k<3>(data, n_view, r0, r1, far_lo, window, far, next, base, status, safe, s);
+}
+
+uint64_t index_lookback(uint32_t window) { return 2ull * window + kIdxLagPad; }
+
 // ---------------------------------------------------------------------------
-// k_match: one workgroup per tile of kMatchTile positions.  The tile's bytes
-// plus the preceding window and the forward links of that range are staged in
-// LDS; each thread then resolves positions tid, tid + 1024, ... of the tile.
+// k_match / k_match_lo: one workgroup per tile of kMatchTile positions.  The
+// tile's bytes plus the preceding window and the forward links of that range
+// are staged in LDS; the threads then claim positions of the tile one by one.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kDataLds = kMaxWindow + kMatchTile + 16 + 272;  // 16: alignment slack, 272: look-ahead + pad
 constexpr uint32_t kNextLds = kMaxWindow + kMatchTile + 16;
@@ -368,32 +470,10 @@ __device__ __forceinline__ uint32_t lds_lcp(const uint8_t *lds, uint32_t so, uin
     return m < cap ? m : cap;
 }
 
-__global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restrict__ data, uint64_t first,
-                                                          uint64_t end, uint64_t chunk_bytes, uint32_t c0,
-                                                          uint32_t tiles_per_chunk, MatchParams mp,
-                                                          const uint16_t *__restrict__ far,
-                                                          const uint16_t *__restrict__ next, uint64_t base,
-                                                          uint32_t *__restrict__ match) {
-    // one LDS image: bytes first (so that byte reads need no base add), links behind them
-    __shared__ __attribute__((aligned(16))) uint8_t s_mem[kDataLds + 2 * kNextLds];
-    __shared__ uint32_t s_counter;  // next unclaimed position of the tile
-    uint8_t *const s_data = s_mem;
-    uint16_t *const s_next = reinterpret_cast<uint16_t *>(s_mem + kDataLds);
-
-    const uint32_t chunk = c0 + blockIdx.x / tiles_per_chunk;
-    const uint32_t tile = blockIdx.x % tiles_per_chunk;
-    const uint64_t cs = first + (uint64_t)chunk * chunk_bytes;
-    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
-    const uint64_t t0 = cs + (uint64_t)tile * kMatchTile;
-    if (t0 >= ce) return;
-    const uint64_t t1 = (t0 + kMatchTile < ce) ? t0 + kMatchTile : ce;
-    const uint64_t w0 = (t0 > mp.window ? t0 - mp.window : 0) & ~(uint64_t)15;  // LDS origin, 16-byte aligned
-    const uint64_t w1 = (t1 + mp.max_len < ce) ? t1 + mp.max_len : ce;          // bytes needed: [w0, w1)
-    const uint32_t nbytes = (uint32_t)(w1 - w0);
-    const uint32_t nlinks = (uint32_t)(t1 - w0);
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) s_counter = 0;
-
+// copies bytes [w0, w0 + nbytes) and links [w0, w0 + nlinks) of the view into LDS
+__device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ data, const uint16_t *__restrict__ next,
+                                           uint64_t base, uint64_t w0, uint32_t nbytes, uint32_t nlinks,
+                                           uint8_t *s_data, uint16_t *s_next, uint32_t tid) {
     // stage bytes: 16-byte vectors when the source is aligned, bytes otherwise
     if (((reinterpret_cast<uintptr_t>(data) + w0) & 15) == 0) {
         const uint4 *src = reinterpret_cast<const uint4 *>(data + w0);
@@ -417,6 +497,46 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
             for (uint32_t i = tid; i < nlinks; i += kMatchThreads) s_next[i] = src[i];
         }
     }
+}
+
+__global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restrict__ data, uint64_t first,
+                                                          uint64_t end, uint64_t chunk_bytes, uint32_t c0,
+                                                          uint32_t tiles_per_chunk, MatchParams mp,
+                                                          uint32_t rec_min, uint32_t emit_term,
+                                                          const uint16_t *__restrict__ far,
+                                                          const uint16_t *__restrict__ next, uint64_t base,
+                                                          uint32_t *__restrict__ match,
+                                                          const uint16_t *__restrict__ far_lo,
+                                                          uint2 *__restrict__ open_list,
+                                                          uint32_t *__restrict__ open_cnt) {
+    // one LDS image: bytes first (so that byte reads need no base add), links behind them
+    __shared__ __attribute__((aligned(16))) uint8_t s_mem[kDataLds + 2 * kNextLds];
+    __shared__ uint32_t s_counter;  // next unclaimed position of the tile
+    __shared__ uint32_t s_nopen;    // positions handed on to level 2
+    uint8_t *const s_data = s_mem;
+    uint16_t *const s_next = reinterpret_cast<uint16_t *>(s_mem + kDataLds);
+
+    const uint32_t chunk = c0 + blockIdx.x / tiles_per_chunk;
+    const uint32_t tile = blockIdx.x % tiles_per_chunk;
+    const uint64_t cs = first + (uint64_t)chunk * chunk_bytes;
+    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+    const uint64_t t0 = cs + (uint64_t)tile * kMatchTile;
+    if (t0 >= ce) {
+        if (emit_term && threadIdx.x == 0) open_cnt[blockIdx.x] = 0;
+        return;
+    }
+    const uint64_t t1 = (t0 + kMatchTile < ce) ? t0 + kMatchTile : ce;
+    const uint64_t w0 = (t0 > mp.window ? t0 - mp.window : 0) & ~(uint64_t)15;  // LDS origin, 16-byte aligned
+    const uint64_t w1 = (t1 + mp.max_len < ce) ? t1 + mp.max_len : ce;          // bytes needed: [w0, w1)
+    const uint32_t nbytes = (uint32_t)(w1 - w0);
+    const uint32_t nlinks = (uint32_t)(t1 - w0);
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        s_counter = 0;
+        s_nopen = 0;
+    }
+
+    stage_tile(data, next, base, w0, nbytes, nlinks, s_data, s_next, tid);
     __syncthreads();
 
     // Search.  Chain lengths are very uneven (Zipf-like), so positions are not bound to threads: a lane claims
@@ -424,50 +544,66 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
     // all lanes run kHeadSteps branch-free "head" steps: one four-byte probe of the candidate and its forward
     // link.  The probe looks at the only place that can still matter: for a candidate too far away to end the
     // search, the four bytes ending at offset `best` (they must all agree for it to beat the best length so
-    // far); for a candidate within max_len of the position, or while nothing has been found, the first three
-    // bytes.  The two rarer kinds of work -- measuring a candidate that survived the probe, and retiring a
+    // far); for a candidate within max_len of the position, or while nothing has been found, the first bytes
+    // (four when only lengths of four or more count here, else three).  The two rarer kinds of work -- measuring a candidate that survived the probe, and retiring a
     // position / claiming the next one -- are deferred until enough lanes of the wave wait for them, so that
     // each of the three code paths runs with most of its lanes active.
     const uint32_t min_len = mp.min_len, max_len = mp.max_len;
     const uint32_t tn = (uint32_t)(t1 - t0);
     const uint32_t pbase = (uint32_t)(t0 - w0);  // LDS offset of tile position 0
     const uint16_t *far_t = far + (t0 - base);
+    const uint16_t *far_lo_t = emit_term ? far_lo + (t0 - base) : far_t;
+    uint2 *open_t = open_list + (uint64_t)blockIdx.x * kMatchTile;
     uint32_t *match_t = match + (t0 - base);
     const uint64_t tail_room = ce - t0;  // bytes from tile position 0 to the end of the chunk
 
-    enum : uint32_t { HEAD = 0, EVAL = 1, FETCH = 2, DONE = 3 };
     constexpr int kHeadSteps = ZG_MATCH_STEPS;  // head steps between checks of the deferred work
-    constexpr uint32_t kEvalBatch = 16, kFetchBatch = 8;
-    uint32_t mode = FETCH, idx = 0, po = pbase, so = pbase, cap = 0, best = 0, bestd = 0, p0 = 0, p1 = 0;
-    uint32_t toff = 0, pt = 0, tmask = 0x00FFFFFFu;  // far-candidate probe: offset, expected bytes, byte mask
+#ifndef ZG_EVAL_BATCH
+#define ZG_EVAL_BATCH 4
+#endif
+#ifndef ZG_FETCH_BATCH
+#define ZG_FETCH_BATCH 2
+#endif
+    constexpr uint32_t kEvalBatch = ZG_EVAL_BATCH, kFetchBatch = ZG_FETCH_BATCH;
+    // what a lane is doing: walking (hd), waiting to have a candidate measured (ev), waiting to retire its
+    // position and claim another (ft), or none of them (no positions left).  Kept as predicates, so that the
+    // bookkeeping of a head step is scalar mask arithmetic.
+    bool hd = false, ev = false, ft = true;
+    uint32_t idx = 0, po = pbase, so = pbase, cap = 0, best = 0, bestd = 0, p0 = 0, p1 = 0;
+    int32_t so_near = 0, so_end = 0;  // candidates at or above: within max_len of the position / past the loop guard
+    const uint32_t mask0 = rec_min >= 4 ? 0xFFFFFFFFu : 0x00FFFFFFu;  // first-bytes probe
+    uint32_t toff = 0, pt = 0, tmask = mask0;  // far-candidate probe: offset, expected bytes, byte mask
+    uint32_t termd = 0;                        // distance of the candidate that ended the search, if one did
     bool has_pos = false;  // a position is loaded and its result is not yet written
     uint32_t nxt_idx = atomicAdd(&s_counter, 1u);
     uint32_t nxt_far = nxt_idx < tn ? far_t[nxt_idx] : 0u;
+    uint32_t nxt_flo = (emit_term && nxt_idx < tn) ? far_lo_t[nxt_idx] : 0u;  // level-2 entry of that position
+    uint32_t cur_flo = 0;
 
     for (;;) {
 #pragma unroll
         for (int step = 0; step < kHeadSteps; step++) {
-            const uint32_t d = po - so;
-            const bool nearby = d <= max_len;  // may end the search: its first bytes decide
+            const bool nearby = (int32_t)so >= so_near;  // may end the search: its first bytes decide
             const uint32_t off = nearby ? 0u : toff;
             const uint32_t want = nearby ? p0 : pt;
-            const uint32_t msk = nearby ? 0x00FFFFFFu : tmask;
+            const uint32_t msk = nearby ? mask0 : tmask;
             const uint32_t w = lds_ld4(s_data, so + off);
             const uint32_t nx = s_next[so];
-            const bool is_head = mode == HEAD;
-            const bool guard_end = d <= min_len;  // loop guard: s + min_len < pos
+            const bool guard_end = (int32_t)so >= so_end;  // loop guard: s + min_len < pos
             const bool survive = ((w ^ want) & msk) == 0;
-            const bool to_adv = is_head & !guard_end & !survive;
-            const bool to_fetch = is_head & (guard_end | (!survive & (nx == 0)));
-            const bool to_eval = is_head & !guard_end & survive;
-            so = to_adv ? so + nx : so;
-            mode = to_fetch ? (uint32_t)FETCH : (to_eval ? (uint32_t)EVAL : mode);
+            const bool to_adv = hd & !guard_end & !survive;
+            const bool to_fetch = hd & (guard_end | (!survive & (nx == 0)));
+            const bool to_eval = hd & !guard_end & survive;
+            so += to_adv ? nx : 0u;
+            hd = to_adv & !to_fetch;
+            ev |= to_eval;
+            ft |= to_fetch;
         }
-        uint32_t n_head = (uint32_t)__popcll(__ballot(mode == HEAD));
-        uint32_t n_eval = (uint32_t)__popcll(__ballot(mode == EVAL));
+        uint32_t n_head = (uint32_t)__popcll(__ballot(hd));
+        uint32_t n_eval = (uint32_t)__popcll(__ballot(ev));
         // ---- measure surviving candidates ----
         if (n_eval >= kEvalBatch || (n_eval != 0 && n_head == 0)) {
-            if (mode == EVAL) {
+            if (ev) {
                 uint32_t m;
                 const uint32_t x0 = lds_ld4(s_data, so) ^ p0;
                 if (x0) {
@@ -491,9 +627,10 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
                 if (m > cap) m = cap;
                 const uint32_t d = po - so;
                 bool finish = false;
-                if (m >= min_len) {
+                if (m >= rec_min) {
                     if (d <= max_len && m + 1 >= d) {  // the growing match reached pos: search over
                         finish = true;
+                        termd = d;
                     } else if (m > best) {
                         best = m;
                         bestd = d;
@@ -505,55 +642,191 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
                 }
                 const uint32_t nx = s_next[so];
                 so += nx;
-                mode = (finish || nx == 0) ? FETCH : HEAD;
+                ev = false;
+                ft = finish || nx == 0;
+                hd = !ft;
             }
-            n_head = (uint32_t)__popcll(__ballot(mode == HEAD));
+            n_head = (uint32_t)__popcll(__ballot(hd));
             n_eval = 0;
         }
         // ---- retire finished positions and claim new ones ----
-        const uint32_t n_fetch = (uint32_t)__popcll(__ballot(mode == FETCH));
+        const uint32_t n_fetch = (uint32_t)__popcll(__ballot(ft));
         if (n_fetch >= kFetchBatch || (n_fetch != 0 && n_head == 0 && n_eval == 0)) {
-            if (mode == FETCH) {
-                if (has_pos) match_t[idx] = best ? ((best << 16) | bestd) : 0u;
+            if (ft) {
+                if (has_pos) {
+                    match_t[idx] = best ? ((best << 16) | bestd) : 0u;
+                    if (best == 0u && cur_flo != 0u) {  // still open, and level 2 has candidates for it
+                        const uint32_t slot = atomicAdd(&s_nopen, 1u);
+                        open_t[slot] = make_uint2(idx | (termd << 16), cur_flo);
+                    }
+                }
                 has_pos = false;
                 if (nxt_idx >= tn) {
-                    mode = DONE;
+                    ft = false;  // no positions left
                 } else {
                     idx = nxt_idx;
                     const uint32_t fd = nxt_far;
+                    cur_flo = nxt_flo;
                     nxt_idx = atomicAdd(&s_counter, 1u);
                     nxt_far = nxt_idx < tn ? far_t[nxt_idx] : 0u;
+                    nxt_flo = (emit_term && nxt_idx < tn) ? far_lo_t[nxt_idx] : 0u;
                     const uint64_t remain = tail_room - idx;
                     cap = remain < (uint64_t)(max_len - 1) ? (uint32_t)remain : max_len - 1;
                     best = 0;
                     bestd = 0;
+                    termd = 0;
                     has_pos = true;
                     // the reference searches only while pos < len - min_len, and records nothing below min_len
-                    if (fd != 0 && remain > min_len && cap >= min_len) {
+                    if (fd != 0 && remain > min_len && cap >= rec_min) {
                         po = pbase + idx;
                         so = po - fd;
+                        so_near = (int32_t)po - (int32_t)max_len;
+                        so_end = (int32_t)po - (int32_t)min_len;
                         p0 = lds_ld4(s_data, po);
                         p1 = lds_ld4(s_data, po + 4);
                         toff = 0;
                         pt = p0;
-                        tmask = 0x00FFFFFFu;
-                        mode = HEAD;
+                        tmask = mask0;
+                        hd = true;
+                        ft = false;
                     }
                 }
             }
         } else if (n_fetch == 0 && n_head == 0 && n_eval == 0) {
+            break;  // no lane has anything left
+        }
+    }
+    if (emit_term) {
+        __syncthreads();
+        if (tid == 0) open_cnt[blockIdx.x] = s_nopen;
+    }
+}
+
+// Level 2: the positions level 1 handed on, as a per-tile list of (tile position | distance of the level-1
+// candidate that ended the search << 16, distance of the farthest three-byte chain member).  Candidates at or
+// below the search-ending distance are not looked at.  Every candidate in reach matches at most four bytes,
+// so four bytes of it decide everything.  Positions without a result keep the 0 level 1 wrote.
+__global__ __launch_bounds__(kMatchThreads) void k_match_lo(const uint8_t *__restrict__ data, uint64_t first,
+                                                             uint64_t end, uint64_t chunk_bytes, uint32_t c0,
+                                                             uint32_t tiles_per_chunk, MatchParams mp,
+                                                             const uint16_t *__restrict__ next, uint64_t base,
+                                                             uint32_t *__restrict__ match,
+                                                             const uint2 *__restrict__ open_list,
+                                                             const uint32_t *__restrict__ open_cnt) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_mem[kDataLds + 2 * kNextLds];
+    __shared__ uint32_t s_counter;  // next unclaimed list entry
+    uint8_t *const s_data = s_mem;
+    uint16_t *const s_next = reinterpret_cast<uint16_t *>(s_mem + kDataLds);
+
+    const uint32_t n_open = open_cnt[blockIdx.x];
+    if (n_open == 0) return;
+    const uint32_t chunk = c0 + blockIdx.x / tiles_per_chunk;
+    const uint32_t tile = blockIdx.x % tiles_per_chunk;
+    const uint64_t cs = first + (uint64_t)chunk * chunk_bytes;
+    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+    const uint64_t t0 = cs + (uint64_t)tile * kMatchTile;
+    const uint64_t t1 = (t0 + kMatchTile < ce) ? t0 + kMatchTile : ce;
+    const uint64_t w0 = (t0 > mp.window ? t0 - mp.window : 0) & ~(uint64_t)15;
+    const uint64_t w1 = (t1 + 8 < ce) ? t1 + 8 : ce;  // four bytes of look-ahead are all this level reads
+    const uint32_t nbytes = (uint32_t)(w1 - w0);
+    const uint32_t nlinks = (uint32_t)(t1 - w0);
+    const uint32_t tid = threadIdx.x;
+    const uint2 *open_t = open_list + (uint64_t)blockIdx.x * kMatchTile;
+    uint32_t *match_t = match + (t0 - base);
+    if (tid == 0) s_counter = 0;
+    stage_tile(data, next, base, w0, nbytes, nlinks, s_data, s_next, tid);
+    __syncthreads();
+
+    const uint32_t min_len = mp.min_len, max_len = mp.max_len;
+    const uint32_t pbase = (uint32_t)(t0 - w0);
+    const uint64_t tail_room = ce - t0;
+
+    enum : uint32_t { HEAD = 0, FETCH = 2, DONE = 3 };
+    constexpr int kSteps = ZG_LO_STEPS;
+#ifndef ZG_LO_FETCH_BATCH
+#define ZG_LO_FETCH_BATCH 4
+#endif
+    constexpr uint32_t kFetchBatch = ZG_LO_FETCH_BATCH;
+    uint32_t mode = FETCH, idx = 0, po = pbase, so = pbase, lim = 0, best = 0, bestd = 0, p0 = 0, termd = 0;
+    bool has_pos = false;
+    uint32_t nxt_i = atomicAdd(&s_counter, 1u);
+    uint2 nxt_ent = nxt_i < n_open ? open_t[nxt_i] : make_uint2(0u, 0u);
+
+    for (;;) {
+#pragma unroll
+        for (int step = 0; step < kSteps; step++) {
+            const uint32_t d = po - so;
+            const uint32_t w = lds_ld4(s_data, so);
+            const uint32_t nx = s_next[so];
+            const bool is_head = mode == HEAD;
+            const uint32_t x = w ^ p0;
+            uint32_t m = ((uint32_t)__ffs((int)x) - 1u) >> 3;  // equal leading bytes; huge when all four agree
+            m = m < lim ? m : lim;
+            const bool stop_pre = (d <= min_len) | (d <= termd);  // loop guard / level-1 end of search
+            const bool good = m >= min_len;
+            const bool ends = good & (d <= m + 1u);               // the growing match reaches pos
+            const bool take = is_head & !stop_pre & good & !ends & (m > best);
+            best = take ? m : best;
+            bestd = take ? d : bestd;
+            const bool fin = is_head & (stop_pre | ends | (take & (m == lim)) | (nx == 0u));
+            so = (is_head & !fin) ? so + nx : so;
+            mode = fin ? (uint32_t)FETCH : mode;
+        }
+        const uint32_t n_head = (uint32_t)__popcll(__ballot(mode == HEAD));
+        const uint32_t n_fetch = (uint32_t)__popcll(__ballot(mode == FETCH));
+        if (n_fetch >= kFetchBatch || (n_fetch != 0 && n_head == 0)) {
+            if (mode == FETCH) {
+                if (has_pos && best) match_t[idx] = (best << 16) | bestd;
+                has_pos = false;
+                if (nxt_i >= n_open) {
+                    mode = DONE;
+                } else {
+                    const uint2 ent = nxt_ent;
+                    nxt_i = atomicAdd(&s_counter, 1u);
+                    nxt_ent = nxt_i < n_open ? open_t[nxt_i] : make_uint2(0u, 0u);
+                    idx = ent.x & 0xFFFFu;
+                    termd = ent.x >> 16;
+                    const uint32_t fd = ent.y;
+                    const uint64_t remain = tail_room - idx;
+                    const uint32_t cap = remain < (uint64_t)(max_len - 1) ? (uint32_t)remain : max_len - 1;
+                    lim = cap < 4u ? cap : 4u;
+                    best = 0;
+                    bestd = 0;
+                    has_pos = true;
+                    if (fd != 0 && remain > min_len && lim >= min_len) {
+                        po = pbase + idx;
+                        so = po - fd;
+                        p0 = lds_ld4(s_data, po);
+                        mode = HEAD;
+                    }
+                }
+            }
+        } else if (n_fetch == 0 && n_head == 0) {
             break;  // every lane is DONE
         }
     }
 }
 
-hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *far,
-                        const uint16_t *next, uint64_t base, uint32_t *match, hipStream_t s) {
+hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, uint32_t rec_min,
+                        const uint16_t *far, const uint16_t *next, uint64_t base, uint32_t *match,
+                        const uint16_t *far_lo, uint2 *open_list, uint32_t *open_cnt, hipStream_t s) {
     if (c1 <= c0) return hipSuccess;
-    const uint32_t tpc = (uint32_t)((g.chunk_bytes + kMatchTile - 1) / kMatchTile);
+    const uint32_t tpc = match_tiles_per_chunk(g.chunk_bytes);
     const uint64_t nblocks = (uint64_t)(c1 - c0) * tpc;
     hipLaunchKernelGGL(k_match, dim3((uint32_t)nblocks), dim3(kMatchThreads), 0, s, g.data, g.first, g.end,
-                       g.chunk_bytes, c0, tpc, mp, far, next, base, match);
+                       g.chunk_bytes, c0, tpc, mp, rec_min, far_lo ? 1u : 0u, far, next, base, match, far_lo,
+                       open_list, open_cnt);
+    return hipGetLastError();
+}
+
+hipError_t launch_match_lo(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *next,
+                           uint64_t base, uint32_t *match, const uint2 *open_list, const uint32_t *open_cnt,
+                           hipStream_t s) {
+    if (c1 <= c0) return hipSuccess;
+    const uint32_t tpc = match_tiles_per_chunk(g.chunk_bytes);
+    const uint64_t nblocks = (uint64_t)(c1 - c0) * tpc;
+    hipLaunchKernelGGL(k_match_lo, dim3((uint32_t)nblocks), dim3(kMatchThreads), 0, s, g.data, g.first, g.end,
+                       g.chunk_bytes, c0, tpc, mp, next, base, match, open_list, open_cnt);
     return hipGetLastError();
 }
 
