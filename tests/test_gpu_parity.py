@@ -24,6 +24,17 @@ def z():
     return zref
 
 
+def _same(got, want, what=""):
+    """Equality of two long sequences; on a mismatch reports the first differing index (pytest's own diff of
+    sequences this long takes minutes)."""
+    if got == want:
+        return
+    n = min(len(got), len(want))
+    i = next((k for k in range(n) if got[k] != want[k]), n)
+    raise AssertionError(f"{what}: lengths {len(got)} / {len(want)}, first difference at {i}: "
+                         f"{list(got[i:i + 4])} != {list(want[i:i + 4])}")
+
+
 def _small_cases():
     rng = random.Random(1234)
     cases = [b"", b"a", b"ab", b"abc", b"abcd", b"aaaa", b"aaaaa", b"a" * 300, b"a" * 1200,
@@ -47,10 +58,10 @@ def test_adler32(za, z):
 def test_lz77_tokens_small(za, z):
     comp = za.zlib_compressor()
     for data in _small_cases():
-        assert comp.compress_packed(data) == z.lz77_zlib(data, fast=True), data[:32]
+        _same(comp.compress_packed(data), z.lz77_zlib(data, fast=True), data[:32])
         if len(data) > 10:
             for start in (1, len(data) // 2, len(data) - 2):
-                assert comp.compress_packed(data, start=start) == z.lz77_zlib(data, start, fast=True)
+                _same(comp.compress_packed(data, start=start), z.lz77_zlib(data, start, fast=True), "")
 
 
 def test_lz77_default_parameters(za, z):
@@ -61,11 +72,11 @@ def test_lz77_default_parameters(za, z):
              b"abcdefghijklmnopqrstuvwxyz" * 100, b"a" * 1000, bytes(range(255))]
     cases += [bytes(rng.choice(b"abcd") for _ in range(2000))]
     for data in cases:
-        assert comp.compress_packed(data) == z.lz77_compress(data), data[:32]
+        _same(comp.compress_packed(data), z.lz77_compress(data), data[:32])
     small, large = za.LZ77Compressor.with_window_size(64), za.LZ77Compressor.with_window_size(1024)
     inp = b"abcdefghijklmnopqrstuvwxyz" * 100
-    assert small.compress_packed(inp) == z.lz77_compress(inp, window=64)
-    assert large.compress_packed(inp) == z.lz77_compress(inp, window=1024)
+    _same(small.compress_packed(inp), z.lz77_compress(inp, window=64), "")
+    _same(large.compress_packed(inp), z.lz77_compress(inp, window=1024), "")
     assert len(small.compress(inp)) > len(large.compress(inp))  # lz77.rs:317-327
 
 
@@ -73,7 +84,7 @@ def test_lz77_tokens_text_and_binary(za, z):
     comp = za.zlib_compressor()
     for kind, n in (("text", 200_000), ("binary", 100_000), ("random", 70_000), ("mixed", 150_000)):
         data = za.corpus(kind, n)
-        assert comp.compress_packed(data) == z.lz77_zlib(data, fast=True), kind
+        _same(comp.compress_packed(data), z.lz77_zlib(data, fast=True), kind)
 
 
 @pytest.mark.parametrize("window,min_len,max_len", [(2048, 3, 258), (4096, 4, 258), (4096, 3, 64), (8192, 6, 258),
@@ -90,7 +101,7 @@ def test_lz77_parameter_sweep(za, z, window, min_len, max_len):
              (b"0123456789abcdef" * 40 + bytes(rng.randrange(256) for _ in range(37))) * 90]
     for data in cases:
         want = z.lz77_compress(data, window=window, min_len=min_len, max_len=max_len)
-        assert comp.compress_packed(data) == want, (window, min_len, max_len, data[:16])
+        _same(comp.compress_packed(data), want, (window, min_len, max_len, data[:16]))
 
 
 def test_far_members_at_the_edge_of_the_window(za, z):
@@ -101,7 +112,27 @@ def test_far_members_at_the_edge_of_the_window(za, z):
     for gap in (32768, 32767, 32766, 32705, 32704, 30000):
         filler = lambda n: bytes(rng.randrange(64) for _ in range(n))
         data = b"".join(marker + filler(gap - len(marker)) for _ in range(5)) + marker + filler(100)
-        assert za.zlib_compressor().compress_packed(data) == z.lz77_zlib(data, fast=True), gap
+        _same(za.zlib_compressor().compress_packed(data), z.lz77_zlib(data, fast=True), gap)
+
+
+def test_long_three_byte_chains(za, z):
+    """Positions whose first three bytes are everywhere in the window but whose fourth is rare: the level-2 walk
+    runs out of its step budget and a whole wave finishes it.  Includes four-byte agreements at distances 4, 5
+    and 6 (the first two end the search instead of being recorded)."""
+    rng = random.Random(5)
+    alphabet = b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz"
+    parts = []
+    for i in range(9000):
+        parts.append(b"xyz" + bytes([rng.choice(alphabet)]) + bytes([rng.randrange(256)]))
+        if i % 1500 == 7:
+            parts.append(b"xyz~" + b"xyz~"[: i % 3 + 1] + b"xyz~Q")  # near repeats right behind a rare fourth byte
+    data = b"".join(parts)
+    comp = za.zlib_compressor()
+    _same(comp.compress_packed(data), z.lz77_zlib(data, fast=True), "xyz chains")
+    comp.min_match_length = 4
+    _same(comp.compress_packed(data), z.lz77_compress(data, window=32768, min_len=4, max_len=258), "min 4")
+    got = za.compress(data, za.Strategy.Dynamic, chunk_bytes=16384)
+    _same(got, z.compress_chunked(data, z.DYNAMIC, 16384, fast=True), "stream")
 
 
 def test_conservative_index_kernel(za, z, monkeypatch):
@@ -111,8 +142,8 @@ def test_conservative_index_kernel(za, z, monkeypatch):
     try:
         for data in (za.corpus("text", 400_000), za.corpus("mixed", 300_000, seed=5), b"a" * 70_000):
             got = za.compress(data, za.Strategy.Dynamic, chunk_bytes=65536, ctx=ctx)
-            assert got == za.compress(data, za.Strategy.Dynamic, chunk_bytes=65536)
-            assert got == z.compress_chunked(data, z.DYNAMIC, 65536, fast=True)
+            _same(got, za.compress(data, za.Strategy.Dynamic, chunk_bytes=65536), "")
+            _same(got, z.compress_chunked(data, z.DYNAMIC, 65536, fast=True), "")
     finally:
         ctx.close()
 
@@ -133,7 +164,7 @@ def test_streams_small(za, z, strategy):
     for data in _small_cases():
         for chunk in (1 << 20, 1024):
             got = za.compress(data, st, chunk_bytes=chunk)
-            assert got == z.compress_chunked(data, zs, chunk, fast=True), (data[:32], chunk)
+            _same(got, z.compress_chunked(data, zs, chunk, fast=True), (data[:32], chunk))
             assert sysz.decompress(got) == data
 
 
@@ -142,7 +173,7 @@ def test_streams_equal_reference_single_chunk(za, z, strategy):
     """n <= chunk_bytes: the stream is the reference crate's stream byte for byte."""
     st, zs = getattr(za.Strategy, strategy), getattr(z, strategy.upper())
     for data in [za.corpus("text", 30_000), za.corpus("text", 3000, seed=7), b"a" * 1200, b"abcd"]:
-        assert za.compress(data, st) == z.compress_reference(data, zs)
+        _same(za.compress(data, st), z.compress_reference(data, zs), "")
 
 
 @pytest.mark.parametrize("kind,n,chunk", [("text", 300_000, 65536), ("mixed", 3 << 20, 1 << 20),
@@ -152,7 +183,7 @@ def test_streams_corpora(za, z, kind, n, chunk):
     data = za.corpus(kind, n)
     got = za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk)
     assert sysz.decompress(got) == data
-    assert got == z.compress_chunked(data, z.DYNAMIC, chunk, fast=True)
+    _same(got, z.compress_chunked(data, z.DYNAMIC, chunk, fast=True), "")
     assert z.decompress(got) == data
 
 
@@ -165,10 +196,10 @@ def test_long_runs_and_periodic_data(za, z):
              bytes(rng.randrange(2) for _ in range(60_000)), b"abcdefgh" * 9000 + bytes(rng.randrange(256) for _ in range(5000))]
     comp = za.zlib_compressor()
     for data in cases:
-        assert comp.compress_packed(data) == z.lz77_zlib(data, fast=True)
+        _same(comp.compress_packed(data), z.lz77_zlib(data, fast=True), "")
         for chunk in (1 << 20, 16384):
             got = za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk)
-            assert got == z.compress_chunked(data, z.DYNAMIC, chunk, fast=True)
+            _same(got, z.compress_chunked(data, z.DYNAMIC, chunk, fast=True), "")
             assert sysz.decompress(got) == data
 
 
@@ -176,13 +207,13 @@ def test_batching_does_not_change_the_stream(za):
     data = za.corpus("text", 700_000)
     a = za.compress(data, za.Strategy.Dynamic, chunk_bytes=65536)
     b = za.compress(data, za.Strategy.Dynamic, chunk_bytes=65536, batch_bytes=131072)
-    assert a == b
+    _same(a, b, "")
 
 
 def test_raw_large(za, z):
     data = za.corpus("random", 1_000_003)
     got = za.compress(data, za.Strategy.Raw)
-    assert got == z.compress_chunked(data, z.RAW, 1 << 20)
+    _same(got, z.compress_chunked(data, z.RAW, 1 << 20), "")
     assert sysz.decompress(got) == data
 
 
@@ -214,5 +245,5 @@ def test_shard_api_assembles_the_single_gpu_stream(za, world, total, chunk):
         for i, v in enumerate(piece[:1]):
             final[off + i] |= v
         final[off + 1:off + nb] = piece[1:]
-    assert bytes(final) == za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk)
+    _same(bytes(final), za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk), "")
     assert sysz.decompress(bytes(final)) == data

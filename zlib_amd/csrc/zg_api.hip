@@ -113,10 +113,22 @@ struct ProfScope {
         }
     }
 };
-#define LAUNCH(id, call)           \
-    do {                           \
-        ProfScope ps_(c, id);      \
-        HIPCHK(call);              \
+// ZLIB_AMD_TRACE=1 names every step on stderr and waits for it: tells which kernel a fault or hang belongs to
+static const bool g_trace = [] {
+    const char *e = std::getenv("ZLIB_AMD_TRACE");
+    return e && e[0] == '1';
+}();
+#define LAUNCH(id, call)                                              \
+    do {                                                              \
+        if (g_trace) fprintf(stderr, "[zlib_amd] %s: %s\n", kKernelNames[id], #call); \
+        {                                                             \
+            ProfScope ps_(c, id);                                     \
+            HIPCHK(call);                                             \
+        }                                                             \
+        if (g_trace) {                                                \
+            HIPCHK(hipStreamSynchronize(c->stream));                  \
+            fprintf(stderr, "[zlib_amd]   done\n");                   \
+        }                                                             \
     } while (0)
 
 void prof_collect(zg_ctx *c) {

@@ -346,36 +346,56 @@ __global__ __launch_bounds__(64) void k_index_d(const uint8_t *__restrict__ data
 }
 
 // k_far_fix: turns the entry distances k_index_d left in far[] into distances of the farthest in-window member.
+// Each thread takes kFixPer positions, 256 apart, so that their dependent link reads overlap.
+constexpr uint32_t kFixPer = 4;
 template <int K>
 __global__ __launch_bounds__(256) void k_far_fix(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t far_lo,
                                                   uint64_t r1, uint32_t window, uint16_t *__restrict__ far,
                                                   const uint16_t *__restrict__ next, uint64_t base) {
-    const uint64_t p = far_lo + (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= r1) return;
-    uint32_t d = far[p - base];
-    if (d <= window) return;
+    const uint64_t p0 = far_lo + (uint64_t)blockIdx.x * (256 * kFixPer) + threadIdx.x;
     const uint32_t d_max = 2u * window + kIdxLagPad - 1u;
-    if (d == 65535u && d_max > 65535u) {
-        // clipped: the entry is the nearest bucket member at distance 65535 or more (no member lies between
-        // it and that distance, or the index would have chosen that one)
-        const uint32_t hp = hash_at<K>(data, p, n_view);
-        uint32_t e = 0;
-        for (uint32_t t = 65535u; t <= d_max && (uint64_t)t <= p; t++)
-            if (hash_at<K>(data, p - t, n_view) == hp) {
-                e = t;
-                break;
-            }
-        d = e;
+    uint32_t d[kFixPer];
+    bool live[kFixPer];
+#pragma unroll
+    for (uint32_t j = 0; j < kFixPer; j++) {
+        const uint64_t p = p0 + j * 256;
+        d[j] = p < r1 ? (uint32_t)far[p - base] : 0u;
+        live[j] = d[j] > window;
     }
-    for (int guard = 0; d > window && guard < 4096; ++guard) {
-        if (p - d < base) {  // cannot happen while the scratch arrays reach index_lookback() behind far_lo
-            d = 0;
-            break;
+#pragma unroll
+    for (uint32_t j = 0; j < kFixPer; j++) {
+        if (live[j] && d[j] == 65535u && d_max > 65535u) {
+            // clipped: the entry is the nearest bucket member at distance 65535 or more (no member lies between
+            // it and that distance, or the index would have chosen that one)
+            const uint64_t p = p0 + j * 256;
+            const uint32_t hp = hash_at<K>(data, p, n_view);
+            uint32_t e = 0;
+            for (uint32_t t = 65535u; t <= d_max && (uint64_t)t <= p; t++)
+                if (hash_at<K>(data, p - t, n_view) == hp) {
+                    e = t;
+                    break;
+                }
+            d[j] = e;
         }
-        const uint32_t nx = next[(p - d) - base];
-        d = nx ? d - nx : 0u;  // a missing link cannot occur on an unbroken chain; treat it as "no candidate"
     }
-    far[p - base] = (uint16_t)(d <= window ? d : 0u);
+    for (int guard = 0; guard < 4096; ++guard) {
+        bool any = false;
+#pragma unroll
+        for (uint32_t j = 0; j < kFixPer; j++) {
+            const uint64_t p = p0 + j * 256;
+            if (d[j] > window) {
+                // a slot below the arrays or a missing link cannot occur on an unbroken chain while the arrays
+                // reach index_lookback() behind far_lo; treated as "no candidate"
+                const uint32_t nx = (p - d[j] >= base) ? (uint32_t)next[(p - d[j]) - base] : 0u;
+                d[j] = nx ? d[j] - nx : 0u;
+                any |= d[j] > window;
+            }
+        }
+        if (!any) break;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kFixPer; j++)
+        if (live[j]) far[(p0 + j * 256) - base] = (uint16_t)(d[j] <= window ? d[j] : 0u);
 }
 
 // k_index_brute: the same two arrays for small windows (LZ77Compressor's default is 144), one thread per
@@ -424,7 +444,8 @@ static hipError_t launch_index_k(const uint8_t *data, uint64_t n_view, uint64_t 
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (r1 > far_lo)
-            hipLaunchKernelGGL(k_far_fix<K>, dim3((uint32_t)((r1 - far_lo + 255) / 256)), dim3(256), 0, s, data, n_view,
+            hipLaunchKernelGGL(k_far_fix<K>, dim3((uint32_t)((r1 - far_lo + 256 * kFixPer - 1) / (256 * kFixPer))),
+                               dim3(256), 0, s, data, n_view,
                                far_lo, r1, window, far, next, base);
     }
     return hipGetLastError();
@@ -706,6 +727,17 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
 // candidate that ended the search << 16, distance of the farthest three-byte chain member).  Candidates at or
 // below the search-ending distance are not looked at.  Every candidate in reach matches at most four bytes,
 // so four bytes of it decide everything.  Positions without a result keep the 0 level 1 wrote.
+//
+// A walk ends at the first four-byte agreement, which a position with a frequent first three bytes and a rare
+// fourth may reach only after thousands of chain members -- one lane busy while the rest of the tile has
+// finished.  A walk that has used up its step budget is therefore parked, and afterwards finished by a whole
+// wave: the 64 lanes compare the window from the walk's current candidate upward directly with the position's
+// four bytes, which finds the same "first agreement" in a bounded number of passes.
+#ifndef ZG_LO_BUDGET
+#define ZG_LO_BUDGET 256
+#endif
+constexpr uint32_t kLoParked = 1024;  // parked walks a tile can hold (12 bytes each)
+
 __global__ __launch_bounds__(kMatchThreads) void k_match_lo(const uint8_t *__restrict__ data, uint64_t first,
                                                              uint64_t end, uint64_t chunk_bytes, uint32_t c0,
                                                              uint32_t tiles_per_chunk, MatchParams mp,
@@ -714,7 +746,9 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lo(const uint8_t *__res
                                                              const uint2 *__restrict__ open_list,
                                                              const uint32_t *__restrict__ open_cnt) {
     __shared__ __attribute__((aligned(16))) uint8_t s_mem[kDataLds + 2 * kNextLds];
-    __shared__ uint32_t s_counter;  // next unclaimed list entry
+    __shared__ uint32_t s_park[kLoParked * 3];  // tile position | end distance << 16, candidate | best << 16, best distance
+    __shared__ uint32_t s_counter;              // next unclaimed list entry
+    __shared__ uint32_t s_nparked;
     uint8_t *const s_data = s_mem;
     uint16_t *const s_next = reinterpret_cast<uint16_t *>(s_mem + kDataLds);
 
@@ -730,10 +764,13 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lo(const uint8_t *__res
     const uint64_t w1 = (t1 + 8 < ce) ? t1 + 8 : ce;  // four bytes of look-ahead are all this level reads
     const uint32_t nbytes = (uint32_t)(w1 - w0);
     const uint32_t nlinks = (uint32_t)(t1 - w0);
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint2 *open_t = open_list + (uint64_t)blockIdx.x * kMatchTile;
     uint32_t *match_t = match + (t0 - base);
-    if (tid == 0) s_counter = 0;
+    if (tid == 0) {
+        s_counter = 0;
+        s_nparked = 0;
+    }
     stage_tile(data, next, base, w0, nbytes, nlinks, s_data, s_next, tid);
     __syncthreads();
 
@@ -741,45 +778,71 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lo(const uint8_t *__res
     const uint32_t pbase = (uint32_t)(t0 - w0);
     const uint64_t tail_room = ce - t0;
 
-    enum : uint32_t { HEAD = 0, FETCH = 2, DONE = 3 };
     constexpr int kSteps = ZG_LO_STEPS;
 #ifndef ZG_LO_FETCH_BATCH
 #define ZG_LO_FETCH_BATCH 4
 #endif
     constexpr uint32_t kFetchBatch = ZG_LO_FETCH_BATCH;
-    uint32_t mode = FETCH, idx = 0, po = pbase, so = pbase, lim = 0, best = 0, bestd = 0, p0 = 0, termd = 0;
+    constexpr uint32_t kBudgetTrips = (ZG_LO_BUDGET + kSteps - 1) / kSteps;
+    bool hd = false, ft = true;  // walking / waiting to retire and claim
+    uint32_t idx = 0, po = pbase, so = pbase, lim = 0, best = 0, bestd = 0, p0 = 0, termd = 0, trips = 0;
     bool has_pos = false;
     uint32_t nxt_i = atomicAdd(&s_counter, 1u);
     uint2 nxt_ent = nxt_i < n_open ? open_t[nxt_i] : make_uint2(0u, 0u);
 
+#ifdef ZG_DEBUG_SPIN
+    uint32_t spin = 0;
+#endif
     for (;;) {
+#ifdef ZG_DEBUG_SPIN
+        if (++spin > 3000000u) {
+            printf("A spin blk %u tid %u hd %d ft %d idx %u so %u po %u lim %u trips %u nxt_i %u n_open %u\n", blockIdx.x, tid,
+                   (int)hd, (int)ft, idx, so, po, lim, trips, nxt_i, n_open);
+            break;
+        }
+#endif
 #pragma unroll
         for (int step = 0; step < kSteps; step++) {
             const uint32_t d = po - so;
             const uint32_t w = lds_ld4(s_data, so);
             const uint32_t nx = s_next[so];
-            const bool is_head = mode == HEAD;
             const uint32_t x = w ^ p0;
             uint32_t m = ((uint32_t)__ffs((int)x) - 1u) >> 3;  // equal leading bytes; huge when all four agree
             m = m < lim ? m : lim;
             const bool stop_pre = (d <= min_len) | (d <= termd);  // loop guard / level-1 end of search
             const bool good = m >= min_len;
             const bool ends = good & (d <= m + 1u);               // the growing match reaches pos
-            const bool take = is_head & !stop_pre & good & !ends & (m > best);
+            const bool take = hd & !stop_pre & good & !ends & (m > best);
             best = take ? m : best;
             bestd = take ? d : bestd;
-            const bool fin = is_head & (stop_pre | ends | (take & (m == lim)) | (nx == 0u));
-            so = (is_head & !fin) ? so + nx : so;
-            mode = fin ? (uint32_t)FETCH : mode;
+            const bool fin = hd & (stop_pre | ends | (take & (m == lim)) | (nx == 0u));
+            so += (hd & !fin) ? nx : 0u;
+            ft |= fin;
+            hd &= !fin;
         }
-        const uint32_t n_head = (uint32_t)__popcll(__ballot(mode == HEAD));
-        const uint32_t n_fetch = (uint32_t)__popcll(__ballot(mode == FETCH));
+        // park walks that have run long (only those still looking for a fourth byte)
+        trips += 1;
+        if (hd && trips >= kBudgetTrips && lim == 4u) {
+            const uint32_t slot = atomicAdd(&s_nparked, 1u);
+            if (slot < kLoParked) {
+                s_park[slot * 3 + 0] = idx | (termd << 16);
+                s_park[slot * 3 + 1] = so | (best << 16);
+                s_park[slot * 3 + 2] = bestd;
+                hd = false;
+                ft = true;
+                has_pos = false;
+            } else {
+                trips = 0;  // no room: walk on
+            }
+        }
+        const uint32_t n_head = (uint32_t)__popcll(__ballot(hd));
+        const uint32_t n_fetch = (uint32_t)__popcll(__ballot(ft));
         if (n_fetch >= kFetchBatch || (n_fetch != 0 && n_head == 0)) {
-            if (mode == FETCH) {
+            if (ft) {
                 if (has_pos && best) match_t[idx] = (best << 16) | bestd;
                 has_pos = false;
                 if (nxt_i >= n_open) {
-                    mode = DONE;
+                    ft = false;  // nothing left to claim
                 } else {
                     const uint2 ent = nxt_ent;
                     nxt_i = atomicAdd(&s_counter, 1u);
@@ -792,17 +855,90 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lo(const uint8_t *__res
                     lim = cap < 4u ? cap : 4u;
                     best = 0;
                     bestd = 0;
+                    trips = 0;
                     has_pos = true;
                     if (fd != 0 && remain > min_len && lim >= min_len) {
                         po = pbase + idx;
                         so = po - fd;
                         p0 = lds_ld4(s_data, po);
-                        mode = HEAD;
+                        hd = true;
+                        ft = false;
                     }
                 }
             }
         } else if (n_fetch == 0 && n_head == 0) {
-            break;  // every lane is DONE
+            break;  // no lane has anything left
+        }
+    }
+    __syncthreads();
+
+    // parked walks, dealt round-robin to the waves
+#ifdef ZG_DEBUG_NO_B
+    const uint32_t n_parked = 0;
+#else
+    const uint32_t n_raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_nparked);
+    const uint32_t n_parked = n_raw < kLoParked ? n_raw : kLoParked;
+#endif
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    for (uint32_t e = wave; e < n_parked; e += kMatchThreads / 64) {
+        const uint32_t e0 = s_park[e * 3 + 0], e1 = s_park[e * 3 + 1], e2 = s_park[e * 3 + 2];
+        const uint32_t pidx = e0 & 0xFFFFu, ptermd = e0 >> 16;
+        const uint32_t s_lo = e1 & 0xFFFFu, pbest = e1 >> 16, pbestd = e2;
+        const uint32_t ppo = pbase + pidx;
+        const uint32_t excl = min_len > ptermd ? min_len : ptermd;  // candidates lie more than this below pos
+        const uint32_t s_hi = ppo - excl;                           // one past the last candidate
+        const uint32_t pp0 = lds_ld4(s_data, ppo);
+        uint32_t first4 = 0xFFFFFFFFu, first3 = 0xFFFFFFFFu;        // lowest candidates agreeing in 4 / 3 bytes
+#ifdef ZG_DEBUG_SPIN
+        if (lane == 0 && (s_hi - s_lo) > 70000u) printf("B range blk %u e %u s_lo %u s_hi %u ppo %u excl %u n_parked %u\n", blockIdx.x, e, s_lo, s_hi, ppo, excl, n_parked);
+#endif
+#ifdef ZG_DEBUG_SPIN
+        uint32_t it = 0;
+#endif
+        for (uint32_t b0 = s_lo; b0 < s_hi; b0 += 256) {
+#ifdef ZG_DEBUG_SPIN
+            if (++it > 300u) {
+                if (lane == 0) printf("B spin blk %u e %u s_lo %u s_hi %u ppo %u excl %u e0 %x e1 %x e2 %x n_parked %u\n", blockIdx.x, e, s_lo, s_hi, ppo, excl, e0, e1, e2, n_parked);
+                break;
+            }
+#endif
+            const uint32_t b = b0 + lane * 4;
+            const uint32_t wa = lds_ld4(s_data, b), wb = lds_ld4(s_data, b + 4);
+            uint32_t h4 = 0xFFFFFFFFu, h3 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 3; j >= 0; j--) {
+                const uint32_t v = j == 0 ? wa : __builtin_amdgcn_alignbyte(wb, wa, (uint32_t)j);
+                const uint32_t x = v ^ pp0;
+                const bool in = b + (uint32_t)j < s_hi;
+                if (in && x == 0u) h4 = b + (uint32_t)j;
+                if (in && (x & 0x00FFFFFFu) == 0u) h3 = b + (uint32_t)j;
+            }
+            // lowest hit over the wave: lanes hold ascending, disjoint ranges
+            const uint64_t m3 = __ballot(h3 != 0xFFFFFFFFu);
+            if (m3 && first3 == 0xFFFFFFFFu)
+                first3 = (uint32_t)__shfl((int)h3, __ffsll((unsigned long long)m3) - 1);
+            const uint64_t m4 = __ballot(h4 != 0xFFFFFFFFu);
+            if (m4) {
+                first4 = (uint32_t)__shfl((int)h4, __ffsll((unsigned long long)m4) - 1);
+                break;
+            }
+        }
+        if (lane == 0) {
+            uint32_t rl = 0, rd = 0;
+            const uint32_t d4 = ppo - first4, d3 = ppo - first3;
+            if (first4 != 0xFFFFFFFFu && d4 >= 6u) {  // four bytes at distance 4 or 5 end the search instead
+                rl = 4;
+                rd = d4;
+            } else if (min_len <= 3u) {
+                if (pbest == 3u) {  // found farther back by the walk
+                    rl = 3;
+                    rd = pbestd;
+                } else if (first3 != 0xFFFFFFFFu && first3 != first4 && d3 >= 5u) {
+                    rl = 3;
+                    rd = d3;
+                }
+            }
+            if (rl) match_t[pidx] = (rl << 16) | rd;
         }
     }
 }
