@@ -80,6 +80,25 @@ size_t zg_compress_bound(size_t n, int strategy, const zg_opts *opts);
 int zg_compress_device(zg_ctx *ctx, const void *d_in, size_t n, int strategy, const zg_opts *opts,
                        void *d_out, size_t out_cap, size_t *out_n);
 
+/* ---- many records, each a zlib stream of its own ----
+ * compress(record, strategy) of the reference (src/compress.rs:51-86) for every
+ * record of a batch at once: record i is in[offsets[i] .. offsets[i+1]), its
+ * stream is out[out_offsets[i] .. out_offsets[i+1]) and is what zg_compress
+ * returns for that record alone whenever the record fits one chunk.  Strategy
+ * ZG_DYNAMIC or ZG_FIXED (others: ZG_ERR_UNSUPPORTED).  *out and *out_offsets
+ * (n_records + 1 entries) are malloc'ed; release with zg_free. */
+int zg_compress_batch(zg_ctx *ctx, const uint8_t *in, const size_t *offsets, size_t n_records, int strategy,
+                      uint8_t **out, size_t **out_offsets);
+
+/* Same on device memory: record i occupies d_len[i] bytes (d_len == NULL: all
+ * `stride` bytes) at d_in + i * stride; stride is a multiple of 1024.  d_out
+ * needs zg_compress_batch_bound bytes, 4-byte aligned; d_out_offsets receives
+ * n_records + 1 byte offsets; *out_bytes the total. */
+size_t zg_compress_batch_bound(size_t stride, size_t n_records, int strategy);
+int zg_compress_batch_device(zg_ctx *ctx, const void *d_in, size_t stride, const uint32_t *d_len,
+                             size_t n_records, int strategy, void *d_out, size_t out_cap,
+                             uint64_t *d_out_offsets, size_t *out_bytes);
+
 /* ---- sharded compress: one rank of a multi-GPU job ----
  * A rank owns `n` input bytes (a whole number of chunks unless it is the last
  * rank) and sees `halo` (<= 32768) bytes of the input that precede them:

@@ -247,3 +247,56 @@ def test_shard_api_assembles_the_single_gpu_stream(za, world, total, chunk):
         final[off + 1:off + nb] = piece[1:]
     _same(bytes(final), za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk), "")
     assert sysz.decompress(bytes(final)) == data
+
+
+def _record_cases(za):
+    rng = random.Random(77)
+    recs = [b"", b"a", b"abc", b"hello hello hello hello", bytes(4096), b"\x01" * 1000,
+            bytes(rng.randrange(256) for _ in range(4096)), b"one repeated phrase " * 200,
+            bytes(rng.randrange(256) for _ in range(777))]
+    recs += [za.corpus("records", 4096, offset=4096 * i) for i in range(12)]
+    recs += [za.corpus("text", n, seed=n) for n in (1, 100, 1023, 1024, 1025, 3000, 4095, 5000)]
+    recs += [za.corpus("binary", 2500, seed=3), za.corpus("mixed", 4096, seed=9)]
+    return recs
+
+
+@pytest.mark.parametrize("strategy", ["Dynamic", "Fixed"])
+def test_record_batch_equals_per_record_compress(za, z, strategy):
+    """zg_compress_batch: every record's stream is compress(record, strategy) -- the reference's single-block
+    stream wherever the reference does not panic -- and records do not see each other."""
+    st, zs = getattr(za.Strategy, strategy), getattr(z, strategy.upper())
+    recs = _record_cases(za)
+    got = za.compress_batch(recs, st)
+    assert len(got) == len(recs)
+    for i, (r, g) in enumerate(zip(recs, got)):
+        _same(g, z.compress_chunked(r, zs, 1 << 20, fast=True), f"record {i} ({len(r)} bytes)")
+        assert sysz.decompress(g) == r
+    # the same records in another order and as equally sized slots (the copy-free layout)
+    got2 = za.compress_batch(recs[::-1], st)
+    assert got2 == got[::-1]
+    same = [za.corpus("records", 4096, offset=4096 * i) for i in range(300)]
+    for r, g in zip(same, za.compress_batch(same, st)):
+        _same(g, z.compress_chunked(r, zs, 1 << 20, fast=True), "equal slots")
+
+
+def test_record_batch_large_records_and_device_entry(za, z):
+    import torch
+    recs = [za.corpus("text", 70_000, seed=1), za.corpus("mixed", 40_000, seed=2), b"", za.corpus("text", 33_000, seed=4)]
+    for r, g in zip(recs, za.compress_batch(recs)):
+        _same(g, z.compress_chunked(r, z.DYNAMIC, 1 << 20, fast=True), len(r))
+    # device entry point, 5000 records of 4 KiB: spans more than one pass over the scratch buffers
+    n, stride = 5000, 4096
+    data = za.corpus("records", n * stride)
+    d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    cap = za.compress_batch_bound(stride, n)
+    d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    d_off = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    total = za.compress_batch_device(d_in.data_ptr(), stride, 0, n, d_out.data_ptr(), cap, d_off.data_ptr())
+    off = d_off.cpu().tolist()
+    out = d_out[:total].cpu().numpy().tobytes()
+    assert off[0] == 0 and off[-1] == total
+    for i in range(0, n, 97):
+        rec = data[i * stride:(i + 1) * stride]
+        assert sysz.decompress(out[off[i]:off[i + 1]]) == rec
+        _same(out[off[i]:off[i + 1]], z.compress_chunked(rec, z.DYNAMIC, 1 << 20, fast=True), i)
+    assert sysz.decompress(out[off[n - 1]:off[n]]) == data[(n - 1) * stride:]

@@ -131,6 +131,45 @@ def compress_device(d_in: int, n: int, d_out: int, out_cap: int, strategy: Strat
     return n_out.value
 
 
+def compress_batch(records: Sequence[bytes], strategy: Strategy = Strategy.Dynamic, *,
+                   ctx: Optional[Context] = None) -> List[bytes]:
+    """[zlib::compress(r, &strategy) for r in records], all records in flight on the GPU at once."""
+    ctx = ctx or default_context()
+    blob = b"".join(bytes(r) for r in records)
+    offs = (C.c_size_t * (len(records) + 1))()
+    pos = 0
+    for i, r in enumerate(records):
+        offs[i] = pos
+        pos += len(r)
+    offs[len(records)] = pos
+    out, out_offs = C.POINTER(C.c_uint8)(), C.POINTER(C.c_size_t)()
+    _check(_lib.lib().zg_compress_batch(ctx.handle, blob, offs, len(records), int(strategy), C.byref(out),
+                                        C.byref(out_offs)), ctx)
+    try:
+        total = out_offs[len(records)]
+        whole = C.string_at(out, total)
+        return [whole[out_offs[i]:out_offs[i + 1]] for i in range(len(records))]
+    finally:
+        _lib.lib().zg_free(out)
+        _lib.lib().zg_free(out_offs)
+
+
+def compress_batch_bound(stride: int, n_records: int, strategy: Strategy = Strategy.Dynamic) -> int:
+    return _lib.lib().zg_compress_batch_bound(stride, n_records, int(strategy))
+
+
+def compress_batch_device(d_in: int, stride: int, d_len: int, n_records: int, d_out: int, out_cap: int,
+                          d_out_offsets: int, strategy: Strategy = Strategy.Dynamic, *,
+                          ctx: Optional[Context] = None) -> int:
+    """Device pointers: records of d_len[i] (uint32; 0 pointer = all `stride`) bytes in slots of `stride` bytes;
+    d_out_offsets receives n_records + 1 uint64 offsets.  Returns the total number of output bytes."""
+    ctx = ctx or default_context()
+    n_out = C.c_size_t()
+    _check(_lib.lib().zg_compress_batch_device(ctx.handle, d_in, stride, d_len, n_records, int(strategy), d_out,
+                                               out_cap, d_out_offsets, C.byref(n_out)), ctx)
+    return n_out.value
+
+
 def shard_begin(d_in: int, halo: int, n: int, strategy: Strategy, last_rank: bool, *, chunk_bytes: int = 0,
                 ctx: Optional[Context] = None) -> ShardInfo:
     ctx = ctx or default_context()

@@ -51,8 +51,9 @@ struct Scalars {
     uint64_t carry;       // absolute bit offset of the next block
     uint64_t out_bytes;   // final size written by k_trailer
     uint32_t adler[2];    // running a, b
-    uint32_t status;      // bit 0: output capacity exceeded
+    uint32_t status;      // bit 0: output capacity exceeded, bit 1: index exchange out of order
     uint32_t pad;
+    uint64_t unused_carry;  // sink for the block-offset scan where only the tile scan is wanted
 };
 
 }  // namespace
@@ -62,7 +63,7 @@ struct zg_ctx {
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::string err;
-    DevBuf far, next, far3, next3, open_list, open_cnt, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
+    DevBuf far, next, far3, next3, open_list, open_cnt, rec_len, rec_off, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
         scalars, stage_in, stage_out, misc, flag, sub_exit, sub_exit2, merged, tile_cnt, adler_blk;
     // shard state kept between zg_shard_begin and zg_shard_finish
     bool shard_active = false;
@@ -214,6 +215,8 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
     const uint64_t ib0 = (bs > back ? bs - back : 0) & ~(uint64_t)15;  // scratch arrays start here
     const uint64_t span = be - ib0;
     const bool two_level = mp.min_len < 5;  // lengths 3 and 4 need the three-byte chains
+    const uint64_t iso_first = g.isolated ? g.first : 0;
+    const uint32_t iso_bytes = g.isolated ? (uint32_t)g.chunk_bytes : 0u;
     const uint32_t rec_min = mp.min_len < 5 ? 5u : mp.min_len;
     HIPCHK(c->far.ensure(span * 2 + 64));
     HIPCHK(c->next.ensure(span * 2 + 64));
@@ -227,14 +230,16 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
         uint32_t *status = &c->scalars.as<Scalars>()->status;
         LAUNCH(K_MISC, hipMemsetAsync(c->next.p, 0, span * 2, c->stream));
         LAUNCH(K_INDEX, launch_index(g.data, g.end, ib0, be, bs, mp.window, 5, c->far.as<uint16_t>(),
-                                     c->next.as<uint16_t>(), ib0, status, c->index_safe, c->stream));
+                                     c->next.as<uint16_t>(), ib0, status, c->index_safe, iso_first, iso_bytes,
+                                     c->stream));
         if (two_level) {
             const uint64_t ntiles = (uint64_t)(c1 - c0) * match_tiles_per_chunk(g.chunk_bytes);
             HIPCHK(c->open_list.ensure(ntiles * kMatchTile * sizeof(uint2)));
             HIPCHK(c->open_cnt.ensure(ntiles * sizeof(uint32_t)));
             LAUNCH(K_MISC, hipMemsetAsync(c->next3.p, 0, span * 2, c->stream));
             LAUNCH(K_INDEX, launch_index(g.data, g.end, ib0, be, bs, mp.window, 3, c->far3.as<uint16_t>(),
-                                         c->next3.as<uint16_t>(), ib0, status, c->index_safe, c->stream));
+                                         c->next3.as<uint16_t>(), ib0, status, c->index_safe, iso_first, iso_bytes,
+                                         c->stream));
             LAUNCH(K_MATCH, launch_match(g, c0, c1, mp, rec_min, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
                                          c->match.as<uint32_t>(), c->far3.as<uint16_t>(), c->open_list.as<uint2>(),
                                          c->open_cnt.as<uint32_t>(), c->stream));
@@ -290,7 +295,7 @@ int run_adler(zg_ctx *c, const uint8_t *data, uint64_t n) {
     const uint64_t nseg = (n + seg - 1) / seg;
     HIPCHK(c->adler_part.ensure(nseg * 2 * sizeof(uint32_t)));
     HIPCHK(c->adler_blk.ensure((nseg / 1024 + 1) * 3 * sizeof(uint64_t)));
-    LAUNCH(K_ADLER, launch_adler(data, n, seg, (uint32_t)nseg, c->adler_part.as<uint32_t>(), c->stream));
+    LAUNCH(K_ADLER, launch_adler(data, n, seg, (uint32_t)nseg, nullptr, c->adler_part.as<uint32_t>(), c->stream));
     LAUNCH(K_ADLER, launch_adler_fold(c->adler_part.as<uint32_t>(), n, seg, (uint32_t)nseg, c->adler_blk.as<uint64_t>(),
                                       sc->adler, c->stream));
     return ZG_OK;
@@ -430,7 +435,7 @@ void zg_destroy(zg_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf *bufs[] = {&c->far, &c->next, &c->far3, &c->next3, &c->open_list, &c->open_cnt, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
+    DevBuf *bufs[] = {&c->far, &c->next, &c->far3, &c->next3, &c->open_list, &c->open_cnt, &c->rec_len, &c->rec_off, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
                       &c->block_bits, &c->bit_off, &c->tile_bits, &c->adler_part, &c->scalars, &c->stage_in,
                       &c->stage_out, &c->misc, &c->flag, &c->sub_exit, &c->sub_exit2, &c->merged, &c->tile_cnt,
                       &c->adler_blk};
@@ -507,6 +512,152 @@ int zg_compress(zg_ctx *ctx, const uint8_t *in, size_t n, int strategy, const zg
     HIPCHK(hipMemcpy(h, c->stage_out.p, got, hipMemcpyDeviceToHost));
     *out = h;
     *out_n = got;
+    return ZG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Record batches: every record is compressed as a zlib stream of its own, i.e. compress(record, strategy)
+// of the reference for each of them (src/compress.rs:51-86), all records in flight together.  A record is
+// one isolated chunk; records sit in slots of `stride` bytes.
+// ---------------------------------------------------------------------------
+size_t zg_compress_batch_bound(size_t stride, size_t n_records, int strategy) {
+    (void)strategy;
+    // per record: header + trailer, block header, a 15-bit code per byte, end of block, padding
+    const size_t per = 6 + kHdrWords * 4 + (stride * 15 + 7) / 8 + 2 + 1;
+    return ((per * n_records + 8) + 3) & ~(size_t)3;
+}
+
+namespace {
+int compress_batch_locked(zg_ctx *c, const uint8_t *d_in, size_t stride, const uint32_t *d_len, size_t n_records,
+                          int strategy, uint8_t *d_out, size_t out_cap, uint64_t *d_off, size_t *out_bytes) {
+    if (strategy != ZG_DYNAMIC && strategy != ZG_FIXED) return ZG_ERR_UNSUPPORTED;
+    if (stride < 1024 || (stride % 1024) != 0 || stride > ((size_t)1 << 30)) return ZG_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(d_out) & 3) != 0) return ZG_ERR_ARG;
+    if (n_records > 0xFFFFFFFFull) return ZG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (out_cap < zg_compress_batch_bound(stride, n_records, strategy)) return ZG_ERR_CAPACITY;
+    int rc = init_scalars(c, 0);  // carry = byte offset of the next stream
+    if (rc) return rc;
+    Scalars *sc = c->scalars.as<Scalars>();
+    if (n_records == 0) {
+        *out_bytes = 0;
+        return ZG_OK;
+    }
+    ChunkGrid g;
+    g.data = d_in;
+    g.first = 0;
+    g.end = (uint64_t)stride * n_records;
+    g.chunk_bytes = stride;
+    g.n_chunks = (uint32_t)n_records;
+    g.chunk_len = d_len;
+    g.isolated = 1;
+    const uint32_t max_tiles = max_tiles_for(stride);
+    size_t bc = ((size_t)128 << 20) / stride;
+    if (bc < 1) bc = 1;
+    if (bc > 32768) bc = 32768;
+    if (bc > n_records) bc = n_records;
+    rc = ensure_chunk_meta(c, bc, max_tiles);
+    if (rc) return rc;
+    HIPCHK(c->adler_part.ensure(bc * 2 * sizeof(uint32_t)));
+    LAUNCH(K_MISC, hipMemsetAsync(d_out, 0, zg_compress_batch_bound(stride, n_records, strategy), c->stream));
+    const MatchParams mp{kMaxWindow, 3, 258};  // get_zlib_compressor, src/compress.rs:451-456
+    for (uint32_t c0 = 0; c0 < g.n_chunks; c0 += (uint32_t)bc) {
+        const uint32_t c1 = (uint32_t)std::min<uint64_t>(g.n_chunks, (uint64_t)c0 + bc);
+        rc = run_front(c, g, c0, c1, mp, strategy, kAllFinal, true);
+        if (rc) return rc;
+        const uint64_t bs = (uint64_t)c0 * stride;
+        LAUNCH(K_TILEBITS, launch_tile_bits(c1 - c0, max_tiles, c->tokens.as<uint32_t>(), g, c0, bs,
+                                            c->ntok.as<uint32_t>(), c->tab.as<uint32_t>(), c->tile_bits.as<uint32_t>(),
+                                            c->stream));
+        LAUNCH(K_OFFSETS, launch_offsets(c1 - c0, max_tiles, c->ntok.as<uint32_t>(), c->tile_bits.as<uint32_t>(),
+                                         c->block_bits.as<uint64_t>(), c->bit_off.as<uint64_t>(), &sc->unused_carry,
+                                         c->stream));
+        LAUNCH(K_OFFSETS, launch_batch_offsets(c1 - c0, c->block_bits.as<uint64_t>(), c->bit_off.as<uint64_t>(),
+                                               &sc->carry, d_off + c0, c->stream));
+        LAUNCH(K_ENCODE, launch_encode(c1 - c0, max_tiles, c->tokens.as<uint32_t>(), g, c0, bs, c->ntok.as<uint32_t>(),
+                                       c->tab.as<uint32_t>(), c->hdr.as<uint32_t>(), c->hdr_bits.as<uint32_t>(),
+                                       c->tile_bits.as<uint32_t>(), c->bit_off.as<uint64_t>(),
+                                       reinterpret_cast<uint32_t *>(d_out), (uint64_t)out_cap * 8, &sc->status,
+                                       c->stream));
+        LAUNCH(K_ADLER, launch_adler(d_in + bs, (uint64_t)(c1 - c0) * stride, stride, c1 - c0,
+                                     d_len ? d_len + c0 : nullptr, c->adler_part.as<uint32_t>(), c->stream));
+        LAUNCH(K_MISC, launch_batch_frame(c1 - c0, c->block_bits.as<uint64_t>(), d_off + c0,
+                                          c->adler_part.as<uint32_t>(), d_out, c->stream));
+    }
+    Scalars h;
+    HIPCHK(hipMemcpyAsync(&h, c->scalars.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->prof) prof_collect(c);
+    if (h.status & 2u) return ZG_ERR_INTERNAL;  // the exchange-order check of the index kernel tripped
+    if (h.status & 1u) return ZG_ERR_CAPACITY;
+    *out_bytes = (size_t)h.carry;
+    return ZG_OK;
+}
+}  // namespace
+
+int zg_compress_batch_device(zg_ctx *ctx, const void *d_in, size_t stride, const uint32_t *d_len, size_t n_records,
+                             int strategy, void *d_out, size_t out_cap, uint64_t *d_out_offsets, size_t *out_bytes) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (!d_out || !out_bytes || !d_out_offsets || (!d_in && n_records)) return ZG_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return compress_batch_locked(c, static_cast<const uint8_t *>(d_in), stride, d_len, n_records, strategy,
+                                 static_cast<uint8_t *>(d_out), out_cap, d_out_offsets, out_bytes);
+}
+
+int zg_compress_batch(zg_ctx *ctx, const uint8_t *in, const size_t *offsets, size_t n_records, int strategy,
+                      uint8_t **out, size_t **out_offsets) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (!out || !out_offsets || !offsets || (!in && n_records && offsets[n_records] != offsets[0])) return ZG_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    size_t max_len = 0;
+    for (size_t i = 0; i < n_records; i++) {
+        if (offsets[i + 1] < offsets[i]) return ZG_ERR_ARG;
+        max_len = std::max(max_len, offsets[i + 1] - offsets[i]);
+    }
+    if (max_len > 0xFFFFFFFFull) return ZG_ERR_ARG;
+    const size_t stride = std::max<size_t>(1024, (max_len + 1023) / 1024 * 1024);
+    // slots of `stride` bytes: a batch of equally long records whose length is a multiple of 1024 is copied as is
+    const bool packed = n_records && max_len == stride && offsets[n_records] - offsets[0] == stride * n_records;
+    std::vector<uint32_t> lens(n_records);
+    for (size_t i = 0; i < n_records; i++) lens[i] = (uint32_t)(offsets[i + 1] - offsets[i]);
+    HIPCHK(c->stage_in.ensure(stride * n_records + 64));
+    HIPCHK(c->rec_len.ensure(n_records * sizeof(uint32_t) + 4));
+    HIPCHK(c->rec_off.ensure((n_records + 1) * sizeof(uint64_t)));
+    if (packed) {
+        HIPCHK(hipMemcpyAsync(c->stage_in.p, in + offsets[0], stride * n_records, hipMemcpyHostToDevice, c->stream));
+    } else if (n_records) {
+        std::vector<uint8_t> slots(stride * n_records, 0);
+        for (size_t i = 0; i < n_records; i++)
+            if (lens[i]) memcpy(slots.data() + i * stride, in + offsets[i], lens[i]);
+        HIPCHK(hipMemcpy(c->stage_in.p, slots.data(), slots.size(), hipMemcpyHostToDevice));
+    }
+    if (n_records)
+        HIPCHK(hipMemcpy(c->rec_len.p, lens.data(), n_records * sizeof(uint32_t), hipMemcpyHostToDevice));
+    const size_t bound = zg_compress_batch_bound(stride, n_records, strategy);
+    HIPCHK(c->stage_out.ensure(bound));
+    size_t got = 0;
+    rc = compress_batch_locked(c, c->stage_in.as<uint8_t>(), stride, c->rec_len.as<uint32_t>(), n_records, strategy,
+                               c->stage_out.as<uint8_t>(), bound, c->rec_off.as<uint64_t>(), &got);
+    if (rc) return rc;
+    uint8_t *h = static_cast<uint8_t *>(malloc(got ? got : 1));
+    size_t *ho = static_cast<size_t *>(malloc((n_records + 1) * sizeof(size_t)));
+    std::vector<uint64_t> off64(n_records + 1, 0);
+    if (!h || !ho) {
+        free(h);
+        free(ho);
+        return ZG_ERR_NOMEM;
+    }
+    if (got) HIPCHK(hipMemcpy(h, c->stage_out.p, got, hipMemcpyDeviceToHost));
+    if (n_records)
+        HIPCHK(hipMemcpy(off64.data(), c->rec_off.p, (n_records + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i <= n_records; i++) ho[i] = (size_t)off64[i];
+    *out = h;
+    *out_offsets = ho;
     return ZG_OK;
 }
 

@@ -28,7 +28,8 @@ __device__ __forceinline__ uint32_t parse_step(const uint32_t *__restrict__ matc
     return len ? len : 1u;
 }
 
-__global__ __launch_bounds__(64) void k_parse_spec(uint64_t first, uint64_t end, uint64_t chunk_bytes, uint32_t c0,
+__global__ __launch_bounds__(64) void k_parse_spec(uint64_t first, uint64_t end, uint64_t chunk_bytes,
+        const uint32_t *__restrict__ clen, uint32_t c0,
                                                     uint32_t n_chunks, uint32_t spc,
                                                     const uint32_t *__restrict__ match, uint64_t base,
                                                     uint8_t *__restrict__ flag, uint32_t *__restrict__ sub_exit) {
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(64) void k_parse_spec(uint64_t first, uint64_t end,
     const uint32_t ci = (uint32_t)(gid / spc), j = (uint32_t)(gid % spc);
     if (ci >= n_chunks) return;
     const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
-    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+    const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
     const uint64_t s0 = cs + (uint64_t)j * kParseSub;
     if (s0 >= ce && !(j == 0)) return;
     const uint64_t s1 = (s0 + kParseSub < ce) ? s0 + kParseSub : ce;
@@ -48,7 +49,8 @@ __global__ __launch_bounds__(64) void k_parse_spec(uint64_t first, uint64_t end,
     sub_exit[(uint64_t)ci * spc + j] = (uint32_t)(p - cs);
 }
 
-__global__ __launch_bounds__(64) void k_parse_fix(uint64_t first, uint64_t end, uint64_t chunk_bytes, uint32_t c0,
+__global__ __launch_bounds__(64) void k_parse_fix(uint64_t first, uint64_t end, uint64_t chunk_bytes,
+        const uint32_t *__restrict__ clen, uint32_t c0,
                                                    uint32_t n_chunks, uint32_t spc,
                                                    const uint32_t *__restrict__ match, uint64_t base,
                                                    uint8_t *__restrict__ flag, const uint32_t *__restrict__ sub_exit,
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(64) void k_parse_fix(uint64_t first, uint64_t end, 
     const uint32_t ci = (uint32_t)(gid / spc), j = (uint32_t)(gid % spc);
     if (ci >= n_chunks) return;
     const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
-    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+    const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
     const uint64_t s0 = cs + (uint64_t)j * kParseSub;
     const uint64_t k = (uint64_t)ci * spc + j;
     if (j == 0) {
@@ -99,13 +101,14 @@ __global__ __launch_bounds__(64) void k_parse_fix(uint64_t first, uint64_t end, 
     merged[k] = met ? 1 : 0;
 }
 
-__global__ __launch_bounds__(64) void k_parse_check(uint64_t first, uint64_t end, uint64_t chunk_bytes, uint32_t c0,
+__global__ __launch_bounds__(64) void k_parse_check(uint64_t first, uint64_t end, uint64_t chunk_bytes,
+        const uint32_t *__restrict__ clen, uint32_t c0,
                                                      uint32_t spc, const uint32_t *__restrict__ match, uint64_t base,
                                                      uint8_t *__restrict__ flag, const uint32_t *__restrict__ sub_exit2,
                                                      const uint8_t *__restrict__ merged) {
     const uint32_t ci = blockIdx.x, lane = threadIdx.x;
     const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
-    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+    const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
     const uint32_t nsub = (uint32_t)((ce - cs + kParseSub - 1) / kParseSub);
     uint32_t bad = 0xFFFFFFFFu;  // first sub-tile that never met its guess
     for (uint32_t j0 = 0; j0 < nsub && bad == 0xFFFFFFFFu; j0 += 64) {
@@ -135,13 +138,14 @@ __global__ __launch_bounds__(64) void k_parse_check(uint64_t first, uint64_t end
 // offsets per chunk, k_emit writes the units and the histograms.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kEmitThreads) void k_emit_count(uint64_t first, uint64_t end, uint64_t chunk_bytes,
-                                                              uint32_t c0, uint32_t tpc,
+                                                              const uint32_t *__restrict__ clen, uint32_t c0,
+                                                              uint32_t tpc,
                                                               const uint8_t *__restrict__ flag, uint64_t base,
                                                               uint32_t *__restrict__ tile_cnt) {
     __shared__ uint32_t s_red[kEmitThreads / 64];
     const uint32_t ci = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
-    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+    const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
     const uint64_t t0 = cs + (uint64_t)tile * kEmitTile;
     uint32_t cnt = 0;
     if (t0 < ce) {
@@ -186,7 +190,8 @@ __global__ __launch_bounds__(256) void k_emit_scan(uint32_t tpc, uint32_t *__res
 }
 
 __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict__ data, uint64_t first, uint64_t end,
-                                                        uint64_t chunk_bytes, uint32_t c0, uint32_t tpc,
+                                                        uint64_t chunk_bytes, const uint32_t *__restrict__ clen,
+                                                        uint32_t c0, uint32_t tpc,
                                                         const uint8_t *__restrict__ flag,
                                                         const uint32_t *__restrict__ match, uint64_t base,
                                                         const uint32_t *__restrict__ tile_off,
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict
     __shared__ uint32_t s_scan[kEmitThreads];
     const uint32_t ci = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
-    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+    const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
     const uint64_t t0 = cs + (uint64_t)tile * kEmitTile;
     if (t0 >= ce) return;
     const uint32_t tn = (uint32_t)((ce - t0 < kEmitTile) ? ce - t0 : kEmitTile);
@@ -257,17 +262,17 @@ hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint
     if (e != hipSuccess) return e;
     const uint64_t lanes = (uint64_t)nc * spc;
     const uint32_t blocks = (uint32_t)((lanes + 63) / 64);
-    hipLaunchKernelGGL(k_parse_spec, dim3(blocks), dim3(64), 0, s, g.first, g.end, g.chunk_bytes, c0, nc, spc, match,
-                       base, flag, sub_exit);
-    hipLaunchKernelGGL(k_parse_fix, dim3(blocks), dim3(64), 0, s, g.first, g.end, g.chunk_bytes, c0, nc, spc, match,
-                       base, flag, sub_exit, sub_exit2, merged);
-    hipLaunchKernelGGL(k_parse_check, dim3(nc), dim3(64), 0, s, g.first, g.end, g.chunk_bytes, c0, spc, match, base,
-                       flag, sub_exit2, merged);
-    hipLaunchKernelGGL(k_emit_count, dim3(tpc, nc), dim3(kEmitThreads), 0, s, g.first, g.end, g.chunk_bytes, c0, tpc,
-                       flag, base, tile_cnt);
+    hipLaunchKernelGGL(k_parse_spec, dim3(blocks), dim3(64), 0, s, g.first, g.end, g.chunk_bytes, g.chunk_len, c0, nc, spc,
+                       match, base, flag, sub_exit);
+    hipLaunchKernelGGL(k_parse_fix, dim3(blocks), dim3(64), 0, s, g.first, g.end, g.chunk_bytes, g.chunk_len, c0, nc, spc,
+                       match, base, flag, sub_exit, sub_exit2, merged);
+    hipLaunchKernelGGL(k_parse_check, dim3(nc), dim3(64), 0, s, g.first, g.end, g.chunk_bytes, g.chunk_len, c0, spc, match,
+                       base, flag, sub_exit2, merged);
+    hipLaunchKernelGGL(k_emit_count, dim3(tpc, nc), dim3(kEmitThreads), 0, s, g.first, g.end, g.chunk_bytes, g.chunk_len, c0,
+                       tpc, flag, base, tile_cnt);
     hipLaunchKernelGGL(k_emit_scan, dim3(nc), dim3(256), 0, s, tpc, tile_cnt, ntok);
-    hipLaunchKernelGGL(k_emit, dim3(tpc, nc), dim3(kEmitThreads), 0, s, g.data, g.first, g.end, g.chunk_bytes, c0, tpc,
-                       flag, match, base, tile_cnt, tokens, tok_base, freq);
+    hipLaunchKernelGGL(k_emit, dim3(tpc, nc), dim3(kEmitThreads), 0, s, g.data, g.first, g.end, g.chunk_bytes, g.chunk_len,
+                       c0, tpc, flag, match, base, tile_cnt, tokens, tok_base, freq);
     return hipGetLastError();
 }
 
@@ -328,7 +333,8 @@ __global__ __launch_bounds__(64) void k_huffman(uint32_t n_chunks, int strategy,
     if (lane == 0) {
         if (s_freq[256] == 0) s_freq[256] = 1;  // "ensure terminating character is encoded", src/huffman.rs:264
         uint64_t payload = 0;
-        s_hbits = build_block(s_freq, s_freq + kDOff, strategy, (int64_t)c == final_chunk, s_tab, s_hdr, &payload,
+        s_hbits = build_block(s_freq, s_freq + kDOff, strategy, (int64_t)c == final_chunk || final_chunk == kAllFinal, s_tab, s_hdr,
+                              &payload,
                               s_work);
         s_payload = payload;
     }
@@ -474,6 +480,69 @@ __global__ __launch_bounds__(256) void k_block_offsets(uint32_t n_chunks, const 
     }
     __syncthreads();
     if (tid == 255) carry[0] = base + s_part[255];
+}
+
+// Record batches: every chunk is a zlib stream of its own, 2 header bytes + its block padded to a byte + 4
+// bytes of Adler-32 (reference src/compress.rs:51-86).  carry[0] is the byte offset of the batch's first
+// stream on entry and of the next batch's on exit.
+__global__ __launch_bounds__(256) void k_batch_offsets(uint32_t n_chunks, const uint64_t *__restrict__ block_bits,
+                                                        uint64_t *__restrict__ bit_off, uint64_t *carry,
+                                                        uint64_t *__restrict__ out_offsets) {
+    __shared__ uint64_t s_part[256];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_chunks + 255) / 256;
+    const uint32_t lo = tid * per, hi = (lo + per < n_chunks) ? lo + per : n_chunks;
+    uint64_t s = 0;
+    for (uint32_t i = lo; i < hi && lo < n_chunks; i++) s += 6 + ((block_bits[i] + 7) >> 3);
+    s_part[tid] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        const uint64_t v = tid >= off ? s_part[tid - off] : 0ull;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    const uint64_t base = carry[0];
+    uint64_t run = base + s_part[tid] - s;
+    for (uint32_t i = lo; i < hi && lo < n_chunks; i++) {
+        out_offsets[i] = run;
+        bit_off[i] = (run + 2) * 8;
+        run += 6 + ((block_bits[i] + 7) >> 3);
+    }
+    __syncthreads();
+    if (tid == 255) {
+        carry[0] = base + s_part[255];
+        out_offsets[n_chunks] = base + s_part[255];  // end of the last stream (the next batch rewrites it)
+    }
+}
+__global__ __launch_bounds__(256) void k_batch_frame(uint32_t n_chunks, const uint64_t *__restrict__ block_bits,
+                                                      const uint64_t *__restrict__ out_offsets,
+                                                      const uint32_t *__restrict__ adler_part,
+                                                      uint8_t *__restrict__ out) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_chunks) return;
+    uint8_t *o = out + out_offsets[c];
+    o[0] = 0x78;  // CMF, src/compress.rs:53-62
+    o[1] = 0x01;  // FLG, src/compress.rs:64-72
+    uint8_t *t = o + 2 + ((block_bits[c] + 7) >> 3);
+    const uint32_t a = adler_part[2 * c], b = adler_part[2 * c + 1];
+    t[0] = (uint8_t)(b >> 8);  // big-endian b << 16 | a, src/compress.rs:82-83
+    t[1] = (uint8_t)b;
+    t[2] = (uint8_t)(a >> 8);
+    t[3] = (uint8_t)a;
+}
+hipError_t launch_batch_offsets(uint32_t n_chunks, const uint64_t *block_bits, uint64_t *bit_off, uint64_t *carry,
+                                uint64_t *out_offsets, hipStream_t s) {
+    if (!n_chunks) return hipSuccess;
+    hipLaunchKernelGGL(k_batch_offsets, dim3(1), dim3(256), 0, s, n_chunks, block_bits, bit_off, carry, out_offsets);
+    return hipGetLastError();
+}
+hipError_t launch_batch_frame(uint32_t n_chunks, const uint64_t *block_bits, const uint64_t *out_offsets,
+                              const uint32_t *adler_part, uint8_t *out, hipStream_t s) {
+    if (!n_chunks) return hipSuccess;
+    hipLaunchKernelGGL(k_batch_frame, dim3((n_chunks + 255) / 256), dim3(256), 0, s, n_chunks, block_bits, out_offsets,
+                       adler_part, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_tile_bits(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *tokens, const ChunkGrid &g,

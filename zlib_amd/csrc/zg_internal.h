@@ -59,15 +59,28 @@ struct ChunkGrid {
     uint64_t end;          // view position one past the last owned byte
     uint64_t chunk_bytes;
     uint32_t n_chunks;     // >= 1 (an empty input has one empty chunk)
+    // record batches: chunk c holds chunk_len[c] (<= chunk_bytes) bytes at its slot when chunk_len is set, and
+    // with `isolated` no chunk sees the input before its own first byte (every chunk is a stream of its own)
+    const uint32_t *chunk_len = nullptr;
+    uint32_t isolated = 0;
 };
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint64_t chunk_end(uint64_t cs, uint64_t chunk_bytes, uint64_t end, const uint32_t *clen,
+                                              uint32_t chunk) {
+    if (clen) return cs + clen[chunk];
+    return (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+}
+#endif
 
 // launchers (each enqueues on `s` and returns the HIP status of the launch)
 // index of positions [r0, r1) by the hash of their first key_bytes (3 or 5) bytes; far[] for [far_lo, r1) only.
 // The arrays start at view position `base`, which must lie index_lookback(window) or more behind far_lo
 // (or at 0), and next[] must be zero on entry.
+// iso_bytes != 0: positions belong to slots of iso_bytes starting at iso_first, and chains never leave a slot
 hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
                         uint32_t window, int key_bytes, uint16_t *far, uint16_t *next, uint64_t base,
-                        uint32_t *status, bool safe, hipStream_t s);
+                        uint32_t *status, bool safe, uint64_t iso_first, uint32_t iso_bytes, hipStream_t s);
 uint64_t index_lookback(uint32_t window);
 // level 1: lengths >= rec_min along the five-byte chains.  With far_lo (the far[] of the three-byte index)
 // it also lists, per tile, the positions it leaves without a length and that have three-byte candidates:
@@ -85,6 +98,7 @@ hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint
                         uint32_t *tile_cnt, uint32_t *tokens, uint64_t tok_base, uint32_t *ntok, uint32_t *freq,
                         hipStream_t s);
 hipError_t launch_histogram(const uint32_t *tokens, uint64_t n, uint32_t *freq, hipStream_t s);
+constexpr int64_t kAllFinal = -2;  // launch_huffman: every chunk's block is the last of its stream
 hipError_t launch_huffman(uint32_t n_chunks, int strategy, const uint32_t *freq, int64_t final_chunk, uint32_t *tab,
                           uint32_t *hdr, uint32_t *hdr_bits, uint64_t *block_bits, hipStream_t s);
 hipError_t launch_tile_bits(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *tokens, const ChunkGrid &g,
@@ -97,8 +111,15 @@ hipError_t launch_encode(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *
                          const uint32_t *hdr, const uint32_t *hdr_bits, const uint32_t *tile_off,
                          const uint64_t *bit_off, uint32_t *out, uint64_t out_cap_bits, uint32_t *status,
                          hipStream_t s);
-hipError_t launch_adler(const uint8_t *data, uint64_t n, uint64_t seg_bytes, uint32_t n_seg, uint32_t *partial,
-                        hipStream_t s);
+// per segment (a, b) of a stream starting at (1, 0); seg_len, when set, holds each segment's byte count
+hipError_t launch_adler(const uint8_t *data, uint64_t n, uint64_t seg_bytes, uint32_t n_seg, const uint32_t *seg_len,
+                        uint32_t *partial, hipStream_t s);
+// record batches: byte offset of every record's stream (running total in carry[0]) and its block's bit offset;
+// then the two header bytes and the Adler-32 around every block
+hipError_t launch_batch_offsets(uint32_t n_chunks, const uint64_t *block_bits, uint64_t *bit_off, uint64_t *carry,
+                                uint64_t *out_offsets, hipStream_t s);
+hipError_t launch_batch_frame(uint32_t n_chunks, const uint64_t *block_bits, const uint64_t *out_offsets,
+                              const uint32_t *adler_part, uint8_t *out, hipStream_t s);
 hipError_t launch_adler_fold(const uint32_t *partial, uint64_t n, uint64_t seg_bytes, uint32_t n_seg,
                              uint64_t *block_part /* 3 words per 1024 segments */, uint32_t *state /* [a, b] running */,
                              hipStream_t s);

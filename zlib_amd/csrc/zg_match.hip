@@ -217,7 +217,8 @@ template <int K>
 __global__ __launch_bounds__(64) void k_index_d(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
                                                  uint64_t r1, uint64_t far_lo, uint32_t window,
                                                  uint16_t *__restrict__ far, uint16_t *__restrict__ next,
-                                                 uint64_t base, uint32_t *status) {
+                                                 uint64_t base, uint32_t *status, uint64_t iso_first,
+                                                 uint32_t iso_bytes) {
     __shared__ uint32_t s_head[kIdxBuckets];   // position + 1, 0 = empty (all three)
     __shared__ uint32_t s_old[kIdxBuckets];
     __shared__ uint32_t s_start[kIdxBuckets];
@@ -274,6 +275,9 @@ __global__ __launch_bounds__(64) void k_index_d(const uint8_t *__restrict__ data
     // Within a group this is safe: the lag keeps every old[] entry behind the window of every lane of the
     // group, and a chain start cannot share its bucket with a lane less than a window before it.
     RawKey<K> cur_m[kIdxGroup], cur_r[kIdxGroup], nxt_m[kIdxGroup], nxt_r[kIdxGroup];
+    // isolated slots: a link may not reach below the first byte of the position's slot.  rel = offset of this
+    // lane's first position of the group inside its slot (slots are >= 1024 bytes, a group spans 256).
+    uint32_t rel = iso_bytes ? (uint32_t)((a0 + lane - iso_first) % iso_bytes) : 0u;
     auto group = [&](uint32_t qg, auto full_c) {
         constexpr bool full = decltype(full_c)::value;  // every lane of the group is a position with K bytes
 #pragma unroll
@@ -303,7 +307,13 @@ __global__ __launch_bounds__(64) void k_index_d(const uint8_t *__restrict__ data
         for (int k = 0; k < (int)kIdxGroup; k++) {
             const uint32_t q = qg + (uint32_t)k * 64 + lane;
             violated |= old1[k] > q;
-            linked[k] = old1[k] != 0u && (q + 1u - old1[k]) <= window;
+            uint32_t reach = window;
+            if (iso_bytes) {
+                uint32_t r = rel + (uint32_t)k * 64;
+                r = r >= iso_bytes ? r - iso_bytes : r;
+                reach = r < window ? r : window;
+            }
+            linked[k] = old1[k] != 0u && (q + 1u - old1[k]) <= reach;
             if (valid[k] && !linked[k]) atomicMax(&s_start[h[k]], q + 1u);
         }
         __builtin_amdgcn_wave_barrier();  // the LDS runs one wave's accesses in program order
@@ -327,6 +337,10 @@ __global__ __launch_bounds__(64) void k_index_d(const uint8_t *__restrict__ data
         for (int k = 0; k < (int)kIdxGroup; k++) {
             cur_m[k] = nxt_m[k];
             cur_r[k] = nxt_r[k];
+        }
+        if (iso_bytes) {
+            rel += 64 * kIdxGroup;
+            rel = rel >= iso_bytes ? rel - iso_bytes : rel;
         }
     };
 #pragma unroll
@@ -404,19 +418,24 @@ template <int K>
 __global__ __launch_bounds__(256) void k_index_brute(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
                                                       uint64_t r1, uint64_t far_lo, uint32_t window,
                                                       uint16_t *__restrict__ far, uint16_t *__restrict__ next,
-                                                      uint64_t base) {
+                                                      uint64_t base, uint64_t iso_first, uint32_t iso_bytes) {
     const uint64_t p = r0 + (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= r1) return;
     uint32_t fd = 0, nd = 0;
     if (p + K <= n_view) {
         const uint32_t h = hash_at<K>(data, p, n_view);
-        const uint64_t lo = p > window ? p - window : 0;
+        uint64_t lo = p > window ? p - window : 0, hi_lim = ~0ull;
+        if (iso_bytes) {  // stay inside the position's slot
+            const uint64_t slot = p - (p - iso_first) % iso_bytes;
+            lo = lo > slot ? lo : slot;
+            hi_lim = slot + iso_bytes;
+        }
         for (uint64_t s = lo; s < p; s++)
             if (hash_at<K>(data, s, n_view) == h) {
                 fd = (uint32_t)(p - s);
                 break;
             }
-        for (uint64_t q = p + 1; q <= p + window && q + K <= n_view; q++)
+        for (uint64_t q = p + 1; q <= p + window && q + K <= n_view && q < hi_lim; q++)
             if (hash_at<K>(data, q, n_view) == h) {
                 nd = (uint32_t)(q - p);
                 break;
@@ -429,18 +448,18 @@ __global__ __launch_bounds__(256) void k_index_brute(const uint8_t *__restrict__
 template <int K>
 static hipError_t launch_index_k(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
                                  uint32_t window, uint16_t *far, uint16_t *next, uint64_t base, uint32_t *status,
-                                 bool safe, hipStream_t s) {
+                                 bool safe, uint64_t iso_first, uint32_t iso_bytes, hipStream_t s) {
     if (window < 2048 || n_view < 64) {
         hipLaunchKernelGGL(k_index_brute<K>, dim3((uint32_t)((r1 - r0 + 255) / 256)), dim3(256), 0, s, data, n_view,
-                           r0, r1, far_lo, window, far, next, base);
-    } else if (safe) {
+                           r0, r1, far_lo, window, far, next, base, iso_first, iso_bytes);
+    } else if (safe && !iso_bytes) {  // the conservative variant has no notion of isolated slots
         const uint64_t nseg = (r1 - r0 + kIdxSegment - 1) / kIdxSegment;
         hipLaunchKernelGGL(k_index<K>, dim3((uint32_t)nseg), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, far,
                            next, base);
     } else {
         const uint64_t nseg = (r1 - r0 + kIdxSegD - 1) / kIdxSegD;
         hipLaunchKernelGGL(k_index_d<K>, dim3((uint32_t)nseg), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window,
-                           far, next, base, status);
+                           far, next, base, status, iso_first, iso_bytes);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (r1 > far_lo)
@@ -453,11 +472,13 @@ static hipError_t launch_index_k(const uint8_t *data, uint64_t n_view, uint64_t 
 
 hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
                         uint32_t window, int key_bytes, uint16_t *far, uint16_t *next, uint64_t base,
-                        uint32_t *status, bool safe, hipStream_t s) {
+                        uint32_t *status, bool safe, uint64_t iso_first, uint32_t iso_bytes, hipStream_t s) {
     if (r1 <= r0) return hipSuccess;
     if (key_bytes == 5)
-        return launch_index_k<5>(data, n_view, r0, r1, far_lo, window, far, next, base, status, safe, s);
-    return launch_index_k<3>(data, n_view, r0, r1, far_lo, window, far, next, base, status, safe, s);
+        return launch_index_k<5>(data, n_view, r0, r1, far_lo, window, far, next, base, status, safe, iso_first,
+                                 iso_bytes, s);
+    return launch_index_k<3>(data, n_view, r0, r1, far_lo, window, far, next, base, status, safe, iso_first,
+                             iso_bytes, s);
 }
 
 uint64_t index_lookback(uint32_t window) { return 2ull * window + kIdxLagPad; }
@@ -521,8 +542,9 @@ __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ data, con
 }
 
 __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restrict__ data, uint64_t first,
-                                                          uint64_t end, uint64_t chunk_bytes, uint32_t c0,
-                                                          uint32_t tiles_per_chunk, MatchParams mp,
+                                                          uint64_t end, uint64_t chunk_bytes,
+                                                          const uint32_t *__restrict__ clen, uint32_t isolated,
+                                                          uint32_t c0, uint32_t tiles_per_chunk, MatchParams mp,
                                                           uint32_t rec_min, uint32_t emit_term,
                                                           const uint16_t *__restrict__ far,
                                                           const uint16_t *__restrict__ next, uint64_t base,
@@ -540,14 +562,16 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
     const uint32_t chunk = c0 + blockIdx.x / tiles_per_chunk;
     const uint32_t tile = blockIdx.x % tiles_per_chunk;
     const uint64_t cs = first + (uint64_t)chunk * chunk_bytes;
-    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+    const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, chunk);
     const uint64_t t0 = cs + (uint64_t)tile * kMatchTile;
     if (t0 >= ce) {
         if (emit_term && threadIdx.x == 0) open_cnt[blockIdx.x] = 0;
         return;
     }
     const uint64_t t1 = (t0 + kMatchTile < ce) ? t0 + kMatchTile : ce;
-    const uint64_t w0 = (t0 > mp.window ? t0 - mp.window : 0) & ~(uint64_t)15;  // LDS origin, 16-byte aligned
+    uint64_t wlo = t0 > mp.window ? t0 - mp.window : 0;
+    if (isolated && wlo < cs) wlo = cs;               // nothing before the chunk's own first byte exists for it
+    const uint64_t w0 = wlo & ~(uint64_t)15;          // LDS origin, 16-byte aligned
     const uint64_t w1 = (t1 + mp.max_len < ce) ? t1 + mp.max_len : ce;          // bytes needed: [w0, w1)
     const uint32_t nbytes = (uint32_t)(w1 - w0);
     const uint32_t nlinks = (uint32_t)(t1 - w0);
@@ -739,8 +763,9 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
 constexpr uint32_t kLoParked = 1024;  // parked walks a tile can hold (12 bytes each)
 
 __global__ __launch_bounds__(kMatchThreads) void k_match_lo(const uint8_t *__restrict__ data, uint64_t first,
-                                                             uint64_t end, uint64_t chunk_bytes, uint32_t c0,
-                                                             uint32_t tiles_per_chunk, MatchParams mp,
+                                                             uint64_t end, uint64_t chunk_bytes,
+                                                             const uint32_t *__restrict__ clen, uint32_t isolated,
+                                                             uint32_t c0, uint32_t tiles_per_chunk, MatchParams mp,
                                                              const uint16_t *__restrict__ next, uint64_t base,
                                                              uint32_t *__restrict__ match,
                                                              const uint2 *__restrict__ open_list,
@@ -757,10 +782,12 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lo(const uint8_t *__res
     const uint32_t chunk = c0 + blockIdx.x / tiles_per_chunk;
     const uint32_t tile = blockIdx.x % tiles_per_chunk;
     const uint64_t cs = first + (uint64_t)chunk * chunk_bytes;
-    const uint64_t ce = (cs + chunk_bytes < end) ? cs + chunk_bytes : end;
+    const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, chunk);
     const uint64_t t0 = cs + (uint64_t)tile * kMatchTile;
     const uint64_t t1 = (t0 + kMatchTile < ce) ? t0 + kMatchTile : ce;
-    const uint64_t w0 = (t0 > mp.window ? t0 - mp.window : 0) & ~(uint64_t)15;
+    uint64_t wlo = t0 > mp.window ? t0 - mp.window : 0;
+    if (isolated && wlo < cs) wlo = cs;
+    const uint64_t w0 = wlo & ~(uint64_t)15;
     const uint64_t w1 = (t1 + 8 < ce) ? t1 + 8 : ce;  // four bytes of look-ahead are all this level reads
     const uint32_t nbytes = (uint32_t)(w1 - w0);
     const uint32_t nlinks = (uint32_t)(t1 - w0);
@@ -950,7 +977,7 @@ hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParam
     const uint32_t tpc = match_tiles_per_chunk(g.chunk_bytes);
     const uint64_t nblocks = (uint64_t)(c1 - c0) * tpc;
     hipLaunchKernelGGL(k_match, dim3((uint32_t)nblocks), dim3(kMatchThreads), 0, s, g.data, g.first, g.end,
-                       g.chunk_bytes, c0, tpc, mp, rec_min, far_lo ? 1u : 0u, far, next, base, match, far_lo,
+                       g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, rec_min, far_lo ? 1u : 0u, far, next, base, match, far_lo,
                        open_list, open_cnt);
     return hipGetLastError();
 }
@@ -962,7 +989,7 @@ hipError_t launch_match_lo(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPa
     const uint32_t tpc = match_tiles_per_chunk(g.chunk_bytes);
     const uint64_t nblocks = (uint64_t)(c1 - c0) * tpc;
     hipLaunchKernelGGL(k_match_lo, dim3((uint32_t)nblocks), dim3(kMatchThreads), 0, s, g.data, g.first, g.end,
-                       g.chunk_bytes, c0, tpc, mp, next, base, match, open_list, open_cnt);
+                       g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, next, base, match, open_list, open_cnt);
     return hipGetLastError();
 }
 

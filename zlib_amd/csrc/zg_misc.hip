@@ -14,10 +14,11 @@ constexpr uint32_t kAdlerMod = 65521;  // ADLER_MODULO, reference src/adler.rs:1
 // computed from the two plain sums s1 = sum x[i], t = sum i*x[i] in 64 bits.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_adler(const uint8_t *__restrict__ data, uint64_t n, uint64_t seg_bytes,
+                                                const uint32_t *__restrict__ seg_len,
                                                 uint32_t *__restrict__ partial) {
     __shared__ uint64_t s_s1[4], s_t[4];
     const uint64_t s0 = (uint64_t)blockIdx.x * seg_bytes;
-    const uint64_t len = (s0 + seg_bytes < n) ? seg_bytes : n - s0;
+    const uint64_t len = seg_len ? (uint64_t)seg_len[blockIdx.x] : ((s0 + seg_bytes < n) ? seg_bytes : n - s0);
     const uint8_t *p = data + s0;
     const uint32_t tid = threadIdx.x;
     uint64_t s1 = 0, t = 0;
@@ -127,10 +128,10 @@ __global__ __launch_bounds__(256) void k_adler_fold2(const uint64_t *__restrict_
     }
 }
 
-hipError_t launch_adler(const uint8_t *data, uint64_t n, uint64_t seg_bytes, uint32_t n_seg, uint32_t *partial,
-                        hipStream_t s) {
+hipError_t launch_adler(const uint8_t *data, uint64_t n, uint64_t seg_bytes, uint32_t n_seg, const uint32_t *seg_len,
+                        uint32_t *partial, hipStream_t s) {
     if (!n_seg) return hipSuccess;
-    hipLaunchKernelGGL(k_adler, dim3(n_seg), dim3(256), 0, s, data, n, seg_bytes, partial);
+    hipLaunchKernelGGL(k_adler, dim3(n_seg), dim3(256), 0, s, data, n, seg_bytes, seg_len, partial);
     return hipGetLastError();
 }
 hipError_t launch_adler_fold(const uint32_t *partial, uint64_t n, uint64_t seg_bytes, uint32_t n_seg,
