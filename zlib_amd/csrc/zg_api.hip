@@ -233,8 +233,8 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
                                      c->next.as<uint16_t>(), ib0, status, c->index_safe, iso_first, iso_bytes,
                                      c->stream));
         if (two_level) {
-            const uint64_t ntiles = (uint64_t)(c1 - c0) * match_tiles_per_chunk(g.chunk_bytes);
-            HIPCHK(c->open_list.ensure(ntiles * kMatchTile * sizeof(uint2)));
+            const uint64_t ntiles = (uint64_t)(c1 - c0) * match_tiles_per_chunk(g);
+            HIPCHK(c->open_list.ensure(ntiles * match_tile_positions(g) * sizeof(uint2)));
             HIPCHK(c->open_cnt.ensure(ntiles * sizeof(uint32_t)));
             LAUNCH(K_MISC, hipMemsetAsync(c->next3.p, 0, span * 2, c->stream));
             LAUNCH(K_INDEX, launch_index(g.data, g.end, ib0, be, bs, mp.window, 3, c->far3.as<uint16_t>(),

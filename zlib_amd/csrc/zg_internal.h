@@ -25,14 +25,12 @@ constexpr uint32_t kIdxSegment = 256 * 1024;  // positions owned by one index wo
 // match kernel geometry
 constexpr uint32_t kMatchTile = 16384;  // positions resolved by one match workgroup
 constexpr uint32_t kMatchThreads = 1024;
+constexpr uint32_t kMatchRecordTile = 4096;  // tile of the small geometry used for isolated chunks up to this size
 
 // parse / emit kernel geometry
 constexpr uint32_t kParseSub = 1024;   // positions per speculative parse sub-tile (> kMaxMatch)
 constexpr uint32_t kEmitTile = 4096;   // positions per unit-emission workgroup
 constexpr uint32_t kEmitThreads = 256;
-inline uint32_t match_tiles_per_chunk(uint64_t chunk_bytes) {
-    return (uint32_t)((chunk_bytes + kMatchTile - 1) / kMatchTile);
-}
 inline uint32_t parse_subs_per_chunk(uint64_t chunk_bytes) {
     return (uint32_t)((chunk_bytes + kParseSub - 1) / kParseSub);
 }
@@ -65,6 +63,15 @@ struct ChunkGrid {
     uint32_t isolated = 0;
 };
 
+// positions one match workgroup resolves, and workgroups per chunk
+inline uint32_t match_tile_positions(const ChunkGrid &g) {
+    return (g.isolated && g.chunk_bytes <= kMatchRecordTile) ? kMatchRecordTile : kMatchTile;
+}
+inline uint32_t match_tiles_per_chunk(const ChunkGrid &g) {
+    const uint32_t t = match_tile_positions(g);
+    return (uint32_t)((g.chunk_bytes + t - 1) / t);
+}
+
 #if defined(__HIPCC__)
 __device__ __forceinline__ uint64_t chunk_end(uint64_t cs, uint64_t chunk_bytes, uint64_t end, const uint32_t *clen,
                                               uint32_t chunk) {
@@ -84,7 +91,7 @@ hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint6
 uint64_t index_lookback(uint32_t window);
 // level 1: lengths >= rec_min along the five-byte chains.  With far_lo (the far[] of the three-byte index)
 // it also lists, per tile, the positions it leaves without a length and that have three-byte candidates:
-// open_list[tile * kMatchTile + i] = (tile position | distance of a search-ending candidate << 16, far_lo),
+// open_list[tile * match_tile_positions(g) + i] = (tile position | distance of a search-ending candidate << 16, far_lo),
 // open_cnt[tile] entries.
 hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, uint32_t rec_min,
                         const uint16_t *far, const uint16_t *next, uint64_t base, uint32_t *match,

@@ -488,8 +488,18 @@ uint64_t index_lookback(uint32_t window) { return 2ull * window + kIdxLagPad; }
 // tile's bytes plus the preceding window and the forward links of that range
 // are staged in LDS; the threads then claim positions of the tile one by one.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kDataLds = kMaxWindow + kMatchTile + 16 + 272;  // 16: alignment slack, 272: look-ahead + pad
-constexpr uint32_t kNextLds = kMaxWindow + kMatchTile + 16;
+// Geometry of a match workgroup: positions per tile, positions of window staged before them, threads, and how
+// many parked level-2 walks it can hold.  GeomStream is the general one; GeomRecord serves isolated chunks
+// (records) of at most 4 KiB, whose window is the record itself -- a twelfth of the LDS, so that many records
+// are resident per CU.
+template <uint32_t kTileT, uint32_t kWinT, uint32_t kThreadsT, uint32_t kParkedT>
+struct MatchGeom {
+    static constexpr uint32_t tile = kTileT, win = kWinT, threads = kThreadsT, parked = kParkedT;
+    static constexpr uint32_t data_lds = kWinT + kTileT + 16 + 272;  // 16: alignment slack, 272: look-ahead + pad
+    static constexpr uint32_t next_lds = kWinT + kTileT + 16;
+};
+using GeomStream = MatchGeom<kMatchTile, kMaxWindow, kMatchThreads, 1024>;
+using GeomRecord = MatchGeom<kMatchRecordTile, 0, 256, 64>;
 
 // four bytes at an arbitrary LDS byte offset, from two aligned dwords
 __device__ __forceinline__ uint32_t lds_ld4(const uint8_t *lds, uint32_t off) {
@@ -515,33 +525,35 @@ __device__ __forceinline__ uint32_t lds_lcp(const uint8_t *lds, uint32_t so, uin
 // copies bytes [w0, w0 + nbytes) and links [w0, w0 + nlinks) of the view into LDS
 __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ data, const uint16_t *__restrict__ next,
                                            uint64_t base, uint64_t w0, uint32_t nbytes, uint32_t nlinks,
-                                           uint8_t *s_data, uint16_t *s_next, uint32_t tid) {
+                                           uint8_t *s_data, uint16_t *s_next, uint32_t tid, uint32_t nthreads,
+                                           uint32_t data_cap) {
     // stage bytes: 16-byte vectors when the source is aligned, bytes otherwise
     if (((reinterpret_cast<uintptr_t>(data) + w0) & 15) == 0) {
         const uint4 *src = reinterpret_cast<const uint4 *>(data + w0);
         uint4 *dst = reinterpret_cast<uint4 *>(s_data);
         const uint32_t nv = nbytes >> 4;
-        for (uint32_t i = tid; i < nv; i += kMatchThreads) dst[i] = src[i];
-        for (uint32_t i = (nv << 4) + tid; i < nbytes; i += kMatchThreads) s_data[i] = data[w0 + i];
+        for (uint32_t i = tid; i < nv; i += nthreads) dst[i] = src[i];
+        for (uint32_t i = (nv << 4) + tid; i < nbytes; i += nthreads) s_data[i] = data[w0 + i];
     } else {
-        for (uint32_t i = tid; i < nbytes; i += kMatchThreads) s_data[i] = data[w0 + i];
+        for (uint32_t i = tid; i < nbytes; i += nthreads) s_data[i] = data[w0 + i];
     }
-    for (uint32_t i = nbytes + tid; i < nbytes + 16 && i < kDataLds; i += kMatchThreads) s_data[i] = 0;
+    for (uint32_t i = nbytes + tid; i < nbytes + 16 && i < data_cap; i += nthreads) s_data[i] = 0;
     {
         const uint16_t *src = next + (w0 - base);
         if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
             const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
             uint4 *d4 = reinterpret_cast<uint4 *>(s_next);
             const uint32_t nv = nlinks >> 3;
-            for (uint32_t i = tid; i < nv; i += kMatchThreads) d4[i] = s4[i];
-            for (uint32_t i = (nv << 3) + tid; i < nlinks; i += kMatchThreads) s_next[i] = src[i];
+            for (uint32_t i = tid; i < nv; i += nthreads) d4[i] = s4[i];
+            for (uint32_t i = (nv << 3) + tid; i < nlinks; i += nthreads) s_next[i] = src[i];
         } else {
-            for (uint32_t i = tid; i < nlinks; i += kMatchThreads) s_next[i] = src[i];
+            for (uint32_t i = tid; i < nlinks; i += nthreads) s_next[i] = src[i];
         }
     }
 }
 
-__global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restrict__ data, uint64_t first,
+template <class G>
+__global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict__ data, uint64_t first,
                                                           uint64_t end, uint64_t chunk_bytes,
                                                           const uint32_t *__restrict__ clen, uint32_t isolated,
                                                           uint32_t c0, uint32_t tiles_per_chunk, MatchParams mp,
@@ -553,22 +565,22 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
                                                           uint2 *__restrict__ open_list,
                                                           uint32_t *__restrict__ open_cnt) {
     // one LDS image: bytes first (so that byte reads need no base add), links behind them
-    __shared__ __attribute__((aligned(16))) uint8_t s_mem[kDataLds + 2 * kNextLds];
+    __shared__ __attribute__((aligned(16))) uint8_t s_mem[G::data_lds + 2 * G::next_lds];
     __shared__ uint32_t s_counter;  // next unclaimed position of the tile
     __shared__ uint32_t s_nopen;    // positions handed on to level 2
     uint8_t *const s_data = s_mem;
-    uint16_t *const s_next = reinterpret_cast<uint16_t *>(s_mem + kDataLds);
+    uint16_t *const s_next = reinterpret_cast<uint16_t *>(s_mem + G::data_lds);
 
     const uint32_t chunk = c0 + blockIdx.x / tiles_per_chunk;
     const uint32_t tile = blockIdx.x % tiles_per_chunk;
     const uint64_t cs = first + (uint64_t)chunk * chunk_bytes;
     const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, chunk);
-    const uint64_t t0 = cs + (uint64_t)tile * kMatchTile;
+    const uint64_t t0 = cs + (uint64_t)tile * G::tile;
     if (t0 >= ce) {
         if (emit_term && threadIdx.x == 0) open_cnt[blockIdx.x] = 0;
         return;
     }
-    const uint64_t t1 = (t0 + kMatchTile < ce) ? t0 + kMatchTile : ce;
+    const uint64_t t1 = (t0 + G::tile < ce) ? t0 + G::tile : ce;
     uint64_t wlo = t0 > mp.window ? t0 - mp.window : 0;
     if (isolated && wlo < cs) wlo = cs;               // nothing before the chunk's own first byte exists for it
     const uint64_t w0 = wlo & ~(uint64_t)15;          // LDS origin, 16-byte aligned
@@ -581,7 +593,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
         s_nopen = 0;
     }
 
-    stage_tile(data, next, base, w0, nbytes, nlinks, s_data, s_next, tid);
+    stage_tile(data, next, base, w0, nbytes, nlinks, s_data, s_next, tid, G::threads, G::data_lds);
     __syncthreads();
 
     // Search.  Chain lengths are very uneven (Zipf-like), so positions are not bound to threads: a lane claims
@@ -598,7 +610,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
     const uint32_t pbase = (uint32_t)(t0 - w0);  // LDS offset of tile position 0
     const uint16_t *far_t = far + (t0 - base);
     const uint16_t *far_lo_t = emit_term ? far_lo + (t0 - base) : far_t;
-    uint2 *open_t = open_list + (uint64_t)blockIdx.x * kMatchTile;
+    uint2 *open_t = open_list + (uint64_t)blockIdx.x * G::tile;
     uint32_t *match_t = match + (t0 - base);
     const uint64_t tail_room = ce - t0;  // bytes from tile position 0 to the end of the chunk
 
@@ -760,9 +772,9 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(const uint8_t *__restri
 #ifndef ZG_LO_BUDGET
 #define ZG_LO_BUDGET 256
 #endif
-constexpr uint32_t kLoParked = 1024;  // parked walks a tile can hold (12 bytes each)
 
-__global__ __launch_bounds__(kMatchThreads) void k_match_lo(const uint8_t *__restrict__ data, uint64_t first,
+template <class G>
+__global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restrict__ data, uint64_t first,
                                                              uint64_t end, uint64_t chunk_bytes,
                                                              const uint32_t *__restrict__ clen, uint32_t isolated,
                                                              uint32_t c0, uint32_t tiles_per_chunk, MatchParams mp,
@@ -770,12 +782,12 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lo(const uint8_t *__res
                                                              uint32_t *__restrict__ match,
                                                              const uint2 *__restrict__ open_list,
                                                              const uint32_t *__restrict__ open_cnt) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_mem[kDataLds + 2 * kNextLds];
-    __shared__ uint32_t s_park[kLoParked * 3];  // tile position | end distance << 16, candidate | best << 16, best distance
+    __shared__ __attribute__((aligned(16))) uint8_t s_mem[G::data_lds + 2 * G::next_lds];
+    __shared__ uint32_t s_park[G::parked * 3];  // tile position | end distance << 16, candidate | best << 16, best distance
     __shared__ uint32_t s_counter;              // next unclaimed list entry
     __shared__ uint32_t s_nparked;
     uint8_t *const s_data = s_mem;
-    uint16_t *const s_next = reinterpret_cast<uint16_t *>(s_mem + kDataLds);
+    uint16_t *const s_next = reinterpret_cast<uint16_t *>(s_mem + G::data_lds);
 
     const uint32_t n_open = open_cnt[blockIdx.x];
     if (n_open == 0) return;
@@ -783,8 +795,8 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lo(const uint8_t *__res
     const uint32_t tile = blockIdx.x % tiles_per_chunk;
     const uint64_t cs = first + (uint64_t)chunk * chunk_bytes;
     const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, chunk);
-    const uint64_t t0 = cs + (uint64_t)tile * kMatchTile;
-    const uint64_t t1 = (t0 + kMatchTile < ce) ? t0 + kMatchTile : ce;
+    const uint64_t t0 = cs + (uint64_t)tile * G::tile;
+    const uint64_t t1 = (t0 + G::tile < ce) ? t0 + G::tile : ce;
     uint64_t wlo = t0 > mp.window ? t0 - mp.window : 0;
     if (isolated && wlo < cs) wlo = cs;
     const uint64_t w0 = wlo & ~(uint64_t)15;
@@ -792,13 +804,13 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lo(const uint8_t *__res
     const uint32_t nbytes = (uint32_t)(w1 - w0);
     const uint32_t nlinks = (uint32_t)(t1 - w0);
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint2 *open_t = open_list + (uint64_t)blockIdx.x * kMatchTile;
+    const uint2 *open_t = open_list + (uint64_t)blockIdx.x * G::tile;
     uint32_t *match_t = match + (t0 - base);
     if (tid == 0) {
         s_counter = 0;
         s_nparked = 0;
     }
-    stage_tile(data, next, base, w0, nbytes, nlinks, s_data, s_next, tid);
+    stage_tile(data, next, base, w0, nbytes, nlinks, s_data, s_next, tid, G::threads, G::data_lds);
     __syncthreads();
 
     const uint32_t min_len = mp.min_len, max_len = mp.max_len;
@@ -851,7 +863,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lo(const uint8_t *__res
         trips += 1;
         if (hd && trips >= kBudgetTrips && lim == 4u) {
             const uint32_t slot = atomicAdd(&s_nparked, 1u);
-            if (slot < kLoParked) {
+            if (slot < G::parked) {
                 s_park[slot * 3 + 0] = idx | (termd << 16);
                 s_park[slot * 3 + 1] = so | (best << 16);
                 s_park[slot * 3 + 2] = bestd;
@@ -904,10 +916,10 @@ __global__ __launch_bounds__(kMatchThreads) void k_match_lo(const uint8_t *__res
     const uint32_t n_parked = 0;
 #else
     const uint32_t n_raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_nparked);
-    const uint32_t n_parked = n_raw < kLoParked ? n_raw : kLoParked;
+    const uint32_t n_parked = n_raw < G::parked ? n_raw : G::parked;
 #endif
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    for (uint32_t e = wave; e < n_parked; e += kMatchThreads / 64) {
+    for (uint32_t e = wave; e < n_parked; e += G::threads / 64) {
         const uint32_t e0 = s_park[e * 3 + 0], e1 = s_park[e * 3 + 1], e2 = s_park[e * 3 + 2];
         const uint32_t pidx = e0 & 0xFFFFu, ptermd = e0 >> 16;
         const uint32_t s_lo = e1 & 0xFFFFu, pbest = e1 >> 16, pbestd = e2;
@@ -974,11 +986,16 @@ hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParam
                         const uint16_t *far, const uint16_t *next, uint64_t base, uint32_t *match,
                         const uint16_t *far_lo, uint2 *open_list, uint32_t *open_cnt, hipStream_t s) {
     if (c1 <= c0) return hipSuccess;
-    const uint32_t tpc = match_tiles_per_chunk(g.chunk_bytes);
+    const uint32_t tpc = match_tiles_per_chunk(g);
     const uint64_t nblocks = (uint64_t)(c1 - c0) * tpc;
-    hipLaunchKernelGGL(k_match, dim3((uint32_t)nblocks), dim3(kMatchThreads), 0, s, g.data, g.first, g.end,
-                       g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, rec_min, far_lo ? 1u : 0u, far, next, base, match, far_lo,
-                       open_list, open_cnt);
+    if (match_tile_positions(g) == kMatchRecordTile)
+        hipLaunchKernelGGL(k_match<GeomRecord>, dim3((uint32_t)nblocks), dim3(GeomRecord::threads), 0, s, g.data,
+                           g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, rec_min,
+                           far_lo ? 1u : 0u, far, next, base, match, far_lo, open_list, open_cnt);
+    else
+        hipLaunchKernelGGL(k_match<GeomStream>, dim3((uint32_t)nblocks), dim3(GeomStream::threads), 0, s, g.data,
+                           g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, rec_min,
+                           far_lo ? 1u : 0u, far, next, base, match, far_lo, open_list, open_cnt);
     return hipGetLastError();
 }
 
@@ -986,10 +1003,16 @@ hipError_t launch_match_lo(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPa
                            uint64_t base, uint32_t *match, const uint2 *open_list, const uint32_t *open_cnt,
                            hipStream_t s) {
     if (c1 <= c0) return hipSuccess;
-    const uint32_t tpc = match_tiles_per_chunk(g.chunk_bytes);
+    const uint32_t tpc = match_tiles_per_chunk(g);
     const uint64_t nblocks = (uint64_t)(c1 - c0) * tpc;
-    hipLaunchKernelGGL(k_match_lo, dim3((uint32_t)nblocks), dim3(kMatchThreads), 0, s, g.data, g.first, g.end,
-                       g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, next, base, match, open_list, open_cnt);
+    if (match_tile_positions(g) == kMatchRecordTile)
+        hipLaunchKernelGGL(k_match_lo<GeomRecord>, dim3((uint32_t)nblocks), dim3(GeomRecord::threads), 0, s, g.data,
+                           g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, next, base, match,
+                           open_list, open_cnt);
+    else
+        hipLaunchKernelGGL(k_match_lo<GeomStream>, dim3((uint32_t)nblocks), dim3(GeomStream::threads), 0, s, g.data,
+                           g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, next, base, match,
+                           open_list, open_cnt);
     return hipGetLastError();
 }
 
