@@ -69,6 +69,17 @@ def upload_corpus(torch, za, kind, seed, offset, n, device):
     return dev
 
 
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel`, as collected with tools/collect_profiles.sh (counters cannot be read from
+    inside the timed process); None when the committed profile has no entry for this workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+            t = json.load(f)["workloads"]
+        return t[workload][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(za, kind, seed, total, chunk):
     """The reference algorithm (oracle, verbatim exhaustive matcher) on this host's cores, on a bounded sample."""
     from oracle import zref
@@ -224,6 +235,7 @@ def main():
         launches_per_step = kn / args.steps
         bytes_per_launch = n * (1.0 + ratio) / max(1.0, launches_per_step)  # this rank's share
         achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9
+        traffic = measured_traffic(args.workload, kname) if world == 1 else None
         line = {
             "metric": f"compress input GB/s ({strat_name})", "value": value, "unit": "GB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -239,7 +251,10 @@ def main():
                                        "chunks sharded over ranks; all_gather of bit totals + payload send to rank 0")
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (separate rocprofv3 --pmc "
+                                         "passes over this command, profiles/r1_traffic.json); null if not collected "
+                                         "for this workload",
                          "kernel_avg_ms": k_avg_ms, "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "algorithmic bytes = input bytes read once + compressed bytes written once"},

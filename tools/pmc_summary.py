@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sums rocprofv3 --pmc counter_collection.csv files per kernel: tools/pmc_summary.py DIR [DIR...] [--kernels a,b]"""
-import collections, csv, glob, sys
+import collections, csv, glob, re, sys
 dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
 want = None
 for a in sys.argv[1:]:
@@ -10,7 +10,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for d in dirs:
     for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].split("::")[-1]
+            m = re.search(r"zg::(k_\w+(?:<\d+>)?)", r["Kernel_Name"])
+            k = m.group(1) if m else r["Kernel_Name"].split("(")[0]
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, v in sorted(agg.items()):
     if want and k not in want:
