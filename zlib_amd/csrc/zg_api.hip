@@ -229,17 +229,17 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
     if (span) {
         uint32_t *status = &c->scalars.as<Scalars>()->status;
         LAUNCH(K_MISC, hipMemsetAsync(c->next.p, 0, span * 2, c->stream));
-        LAUNCH(K_INDEX, launch_index(g.data, g.end, ib0, be, bs, mp.window, 5, c->far.as<uint16_t>(),
-                                     c->next.as<uint16_t>(), ib0, status, c->index_safe, iso_first, iso_bytes,
-                                     c->stream));
         if (two_level) {
             const uint64_t ntiles = (uint64_t)(c1 - c0) * match_tiles_per_chunk(g);
             HIPCHK(c->open_list.ensure(ntiles * match_tile_positions(g) * sizeof(uint2)));
             HIPCHK(c->open_cnt.ensure(ntiles * sizeof(uint32_t)));
             LAUNCH(K_MISC, hipMemsetAsync(c->next3.p, 0, span * 2, c->stream));
-            LAUNCH(K_INDEX, launch_index(g.data, g.end, ib0, be, bs, mp.window, 3, c->far3.as<uint16_t>(),
-                                         c->next3.as<uint16_t>(), ib0, status, c->index_safe, iso_first, iso_bytes,
-                                         c->stream));
+        }
+        LAUNCH(K_INDEX, launch_index(g.data, g.end, ib0, be, bs, mp.window, 5, c->far.as<uint16_t>(),
+                                     c->next.as<uint16_t>(), two_level ? 3 : 0, c->far3.as<uint16_t>(),
+                                     c->next3.as<uint16_t>(), ib0, status, c->index_safe, iso_first, iso_bytes,
+                                     c->stream));
+        if (two_level) {
             LAUNCH(K_MATCH, launch_match(g, c0, c1, mp, rec_min, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
                                          c->match.as<uint32_t>(), c->far3.as<uint16_t>(), c->open_list.as<uint2>(),
                                          c->open_cnt.as<uint32_t>(), c->stream));

@@ -84,10 +84,12 @@ __device__ __forceinline__ uint64_t chunk_end(uint64_t cs, uint64_t chunk_bytes,
 // index of positions [r0, r1) by the hash of their first key_bytes (3 or 5) bytes; far[] for [far_lo, r1) only.
 // The arrays start at view position `base`, which must lie index_lookback(window) or more behind far_lo
 // (or at 0), and next[] must be zero on entry.
-// iso_bytes != 0: positions belong to slots of iso_bytes starting at iso_first, and chains never leave a slot
+// iso_bytes != 0: positions belong to slots of iso_bytes starting at iso_first, and chains never leave a slot.
+// Builds the index for key length key_a and, unless key_b is 0, a second one for key_b in the same launches.
 hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
-                        uint32_t window, int key_bytes, uint16_t *far, uint16_t *next, uint64_t base,
-                        uint32_t *status, bool safe, uint64_t iso_first, uint32_t iso_bytes, hipStream_t s);
+                        uint32_t window, int key_a, uint16_t *far_a, uint16_t *next_a, int key_b, uint16_t *far_b,
+                        uint16_t *next_b, uint64_t base, uint32_t *status, bool safe, uint64_t iso_first,
+                        uint32_t iso_bytes, hipStream_t s);
 uint64_t index_lookback(uint32_t window);
 // level 1: lengths >= rec_min along the five-byte chains.  With far_lo (the far[] of the three-byte index)
 // it also lists, per tile, the positions it leaves without a length and that have three-byte candidates:

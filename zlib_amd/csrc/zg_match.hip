@@ -206,7 +206,10 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t *__restrict__ data, 
 // beyond the window, clipped at 65535) in far[]; k_far_fix follows the links afterwards.
 // The warm-up before a segment is 2 * window + 64 * kIdxGroup positions: enough for every old[] entry that
 // can matter.
-constexpr uint32_t kIdxSegD = 128 * 1024;  // positions owned by one k_index_d workgroup
+#ifndef ZG_IDX_SEG_KB
+#define ZG_IDX_SEG_KB 192
+#endif
+constexpr uint32_t kIdxSegD = ZG_IDX_SEG_KB * 1024;  // positions owned by one k_index_d workgroup
 #ifndef ZG_IDX_GROUP
 #define ZG_IDX_GROUP 4
 #endif
@@ -214,17 +217,14 @@ constexpr uint32_t kIdxGroup = ZG_IDX_GROUP;        // batches of 64 positions h
 constexpr uint32_t kIdxLagPad = 64 * kIdxGroup;
 
 template <int K>
-__global__ __launch_bounds__(64) void k_index_d(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
-                                                 uint64_t r1, uint64_t far_lo, uint32_t window,
-                                                 uint16_t *__restrict__ far, uint16_t *__restrict__ next,
-                                                 uint64_t base, uint32_t *status, uint64_t iso_first,
-                                                 uint32_t iso_bytes) {
-    __shared__ uint32_t s_head[kIdxBuckets];   // position + 1, 0 = empty (all three)
-    __shared__ uint32_t s_old[kIdxBuckets];
-    __shared__ uint32_t s_start[kIdxBuckets];
-
+__device__ __forceinline__ void index_d_segment(uint32_t *s_head, uint32_t *s_old, uint32_t *s_start, uint32_t seg,
+                                                const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
+                                                uint64_t r1, uint64_t far_lo, uint32_t window,
+                                                uint16_t *__restrict__ far, uint16_t *__restrict__ next,
+                                                uint64_t base, uint32_t *status, uint64_t iso_first,
+                                                uint32_t iso_bytes) {
     const uint32_t lane = threadIdx.x;
-    const uint64_t a = r0 + (uint64_t)blockIdx.x * kIdxSegD;
+    const uint64_t a = r0 + (uint64_t)seg * kIdxSegD;
     if (a >= r1) return;
     const uint64_t b = (a + kIdxSegD < r1) ? a + kIdxSegD : r1;
     const uint32_t lag = window + kIdxLagPad;
@@ -359,13 +359,35 @@ __global__ __launch_bounds__(64) void k_index_d(const uint8_t *__restrict__ data
     if (__any(violated) && lane == 0) atomicOr(status, 2u);
 }
 
+// One workgroup (one wave) per segment and key length: blockIdx.y selects the five-byte or the three-byte
+// index, so that both are built by one launch and share the machine.
+__global__ __launch_bounds__(64) void k_index_d(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
+                                                 uint64_t r1, uint64_t far_lo, uint32_t window, int key_a, int key_b,
+                                                 uint16_t *__restrict__ far_a, uint16_t *__restrict__ next_a,
+                                                 uint16_t *__restrict__ far_b, uint16_t *__restrict__ next_b,
+                                                 uint64_t base, uint32_t *status, uint64_t iso_first,
+                                                 uint32_t iso_bytes) {
+    __shared__ uint32_t s_head[kIdxBuckets];   // position + 1, 0 = empty (all three)
+    __shared__ uint32_t s_old[kIdxBuckets];
+    __shared__ uint32_t s_start[kIdxBuckets];
+    const int key = blockIdx.y == 0 ? key_a : key_b;
+    uint16_t *far = blockIdx.y == 0 ? far_a : far_b;
+    uint16_t *next = blockIdx.y == 0 ? next_a : next_b;
+    if (key == 5)
+        index_d_segment<5>(s_head, s_old, s_start, blockIdx.x, data, n_view, r0, r1, far_lo, window, far, next, base,
+                           status, iso_first, iso_bytes);
+    else
+        index_d_segment<3>(s_head, s_old, s_start, blockIdx.x, data, n_view, r0, r1, far_lo, window, far, next, base,
+                           status, iso_first, iso_bytes);
+}
+
 // k_far_fix: turns the entry distances k_index_d left in far[] into distances of the farthest in-window member.
 // Each thread takes kFixPer positions, 256 apart, so that their dependent link reads overlap.
 constexpr uint32_t kFixPer = 4;
 template <int K>
-__global__ __launch_bounds__(256) void k_far_fix(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t far_lo,
-                                                  uint64_t r1, uint32_t window, uint16_t *__restrict__ far,
-                                                  const uint16_t *__restrict__ next, uint64_t base) {
+__device__ __forceinline__ void far_fix_block(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t far_lo,
+                                              uint64_t r1, uint32_t window, uint16_t *__restrict__ far,
+                                              const uint16_t *__restrict__ next, uint64_t base) {
     const uint64_t p0 = far_lo + (uint64_t)blockIdx.x * (256 * kFixPer) + threadIdx.x;
     const uint32_t d_max = 2u * window + kIdxLagPad - 1u;
     uint32_t d[kFixPer];
@@ -412,6 +434,20 @@ __global__ __launch_bounds__(256) void k_far_fix(const uint8_t *__restrict__ dat
         if (live[j]) far[(p0 + j * 256) - base] = (uint16_t)(d[j] <= window ? d[j] : 0u);
 }
 
+__global__ __launch_bounds__(256) void k_far_fix(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t far_lo,
+                                                  uint64_t r1, uint32_t window, int key_a, int key_b,
+                                                  uint16_t *__restrict__ far_a, const uint16_t *__restrict__ next_a,
+                                                  uint16_t *__restrict__ far_b, const uint16_t *__restrict__ next_b,
+                                                  uint64_t base) {
+    const int key = blockIdx.y == 0 ? key_a : key_b;
+    uint16_t *far = blockIdx.y == 0 ? far_a : far_b;
+    const uint16_t *next = blockIdx.y == 0 ? next_a : next_b;
+    if (key == 5)
+        far_fix_block<5>(data, n_view, far_lo, r1, window, far, next, base);
+    else
+        far_fix_block<3>(data, n_view, far_lo, r1, window, far, next, base);
+}
+
 // k_index_brute: the same two arrays for small windows (LZ77Compressor's default is 144), one thread per
 // position, by direct scan of the window on either side.
 template <int K>
@@ -446,39 +482,51 @@ __global__ __launch_bounds__(256) void k_index_brute(const uint8_t *__restrict__
 }
 
 template <int K>
-static hipError_t launch_index_k(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
-                                 uint32_t window, uint16_t *far, uint16_t *next, uint64_t base, uint32_t *status,
-                                 bool safe, uint64_t iso_first, uint32_t iso_bytes, hipStream_t s) {
-    if (window < 2048 || n_view < 64) {
+static hipError_t launch_index_slow(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
+                                    uint32_t window, uint16_t *far, uint16_t *next, uint64_t base, bool brute,
+                                    uint64_t iso_first, uint32_t iso_bytes, hipStream_t s) {
+    if (brute) {
         hipLaunchKernelGGL(k_index_brute<K>, dim3((uint32_t)((r1 - r0 + 255) / 256)), dim3(256), 0, s, data, n_view,
                            r0, r1, far_lo, window, far, next, base, iso_first, iso_bytes);
-    } else if (safe && !iso_bytes) {  // the conservative variant has no notion of isolated slots
+    } else {
         const uint64_t nseg = (r1 - r0 + kIdxSegment - 1) / kIdxSegment;
         hipLaunchKernelGGL(k_index<K>, dim3((uint32_t)nseg), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, far,
                            next, base);
-    } else {
-        const uint64_t nseg = (r1 - r0 + kIdxSegD - 1) / kIdxSegD;
-        hipLaunchKernelGGL(k_index_d<K>, dim3((uint32_t)nseg), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window,
-                           far, next, base, status, iso_first, iso_bytes);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        if (r1 > far_lo)
-            hipLaunchKernelGGL(k_far_fix<K>, dim3((uint32_t)((r1 - far_lo + 256 * kFixPer - 1) / (256 * kFixPer))),
-                               dim3(256), 0, s, data, n_view,
-                               far_lo, r1, window, far, next, base);
     }
     return hipGetLastError();
 }
 
+// key_b == 0: one index only
 hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
-                        uint32_t window, int key_bytes, uint16_t *far, uint16_t *next, uint64_t base,
-                        uint32_t *status, bool safe, uint64_t iso_first, uint32_t iso_bytes, hipStream_t s) {
+                        uint32_t window, int key_a, uint16_t *far_a, uint16_t *next_a, int key_b, uint16_t *far_b,
+                        uint16_t *next_b, uint64_t base, uint32_t *status, bool safe, uint64_t iso_first,
+                        uint32_t iso_bytes, hipStream_t s) {
     if (r1 <= r0) return hipSuccess;
-    if (key_bytes == 5)
-        return launch_index_k<5>(data, n_view, r0, r1, far_lo, window, far, next, base, status, safe, iso_first,
-                                 iso_bytes, s);
-    return launch_index_k<3>(data, n_view, r0, r1, far_lo, window, far, next, base, status, safe, iso_first,
-                             iso_bytes, s);
+    const bool brute = window < 2048 || n_view < 64;
+    if (brute || (safe && !iso_bytes)) {  // the conservative variant has no notion of isolated slots
+        for (int which = 0; which < (key_b ? 2 : 1); which++) {
+            const int key = which ? key_b : key_a;
+            uint16_t *far = which ? far_b : far_a, *next = which ? next_b : next_a;
+            const hipError_t e =
+                key == 5 ? launch_index_slow<5>(data, n_view, r0, r1, far_lo, window, far, next, base, brute, iso_first,
+                                                iso_bytes, s)
+                         : launch_index_slow<3>(data, n_view, r0, r1, far_lo, window, far, next, base, brute, iso_first,
+                                                iso_bytes, s);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    const uint32_t ny = key_b ? 2u : 1u;
+    const uint64_t nseg = (r1 - r0 + kIdxSegD - 1) / kIdxSegD;
+    hipLaunchKernelGGL(k_index_d, dim3((uint32_t)nseg, ny), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, key_a,
+                       key_b, far_a, next_a, far_b, next_b, base, status, iso_first, iso_bytes);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (r1 > far_lo)
+        hipLaunchKernelGGL(k_far_fix, dim3((uint32_t)((r1 - far_lo + 256 * kFixPer - 1) / (256 * kFixPer)), ny),
+                           dim3(256), 0, s, data, n_view, far_lo, r1, window, key_a, key_b, far_a, next_a, far_b, next_b,
+                           base);
+    return hipGetLastError();
 }
 
 uint64_t index_lookback(uint32_t window) { return 2ull * window + kIdxLagPad; }
