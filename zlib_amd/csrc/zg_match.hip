@@ -661,6 +661,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     uint2 *open_t = open_list + (uint64_t)blockIdx.x * G::tile;
     uint32_t *match_t = match + (t0 - base);
     const uint64_t tail_room = ce - t0;  // bytes from tile position 0 to the end of the chunk
+    const uint32_t tail_room32 = tail_room < 0x7FFFFFFFull ? (uint32_t)tail_room : 0x7FFFFFFFu;
 
     constexpr int kHeadSteps = ZG_MATCH_STEPS;  // head steps between checks of the deferred work
 #ifndef ZG_EVAL_BATCH
@@ -758,6 +759,11 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
         const uint32_t n_fetch = (uint32_t)__popcll(__ballot(ft));
         if (n_fetch >= kFetchBatch || (n_fetch != 0 && n_head == 0 && n_eval == 0)) {
             if (ft) {
+                // Order matters for the memory counter, which retires in issue order: first take the values
+                // prefetched by the previous visit (nothing younger is in flight, so this costs no wait), then
+                // issue this visit's stores and, last, the loads for the next position.
+                uint32_t fd = nxt_far, flo = nxt_flo;
+                asm volatile("" : "+v"(fd), "+v"(flo));
                 if (has_pos) {
                     match_t[idx] = best ? ((best << 16) | bestd) : 0u;
                     if (best == 0u && cur_flo != 0u) {  // still open, and level 2 has candidates for it
@@ -770,19 +776,15 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                     ft = false;  // no positions left
                 } else {
                     idx = nxt_idx;
-                    const uint32_t fd = nxt_far;
-                    cur_flo = nxt_flo;
-                    nxt_idx = atomicAdd(&s_counter, 1u);
-                    nxt_far = nxt_idx < tn ? far_t[nxt_idx] : 0u;
-                    nxt_flo = (emit_term && nxt_idx < tn) ? far_lo_t[nxt_idx] : 0u;
-                    const uint64_t remain = tail_room - idx;
-                    cap = remain < (uint64_t)(max_len - 1) ? (uint32_t)remain : max_len - 1;
+                    cur_flo = emit_term ? flo : 0u;
+                    const uint32_t remain32 = tail_room32 - idx;  // bytes to the end of the chunk, saturated
+                    cap = remain32 < max_len - 1 ? remain32 : max_len - 1;
                     best = 0;
                     bestd = 0;
                     termd = 0;
                     has_pos = true;
                     // the reference searches only while pos < len - min_len, and records nothing below min_len
-                    if (fd != 0 && remain > min_len && cap >= rec_min) {
+                    if (fd != 0 && remain32 > min_len && cap >= rec_min) {
                         po = pbase + idx;
                         so = po - fd;
                         so_near = (int32_t)po - (int32_t)max_len;
@@ -795,6 +797,10 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                         hd = true;
                         ft = false;
                     }
+                    nxt_idx = atomicAdd(&s_counter, 1u);
+                    const uint32_t ni = nxt_idx < tn ? nxt_idx : 0u;  // unconditional loads: tn >= 1 here
+                    nxt_far = far_t[ni];
+                    nxt_flo = far_lo_t[ni];
                 }
             }
         } else if (n_fetch == 0 && n_head == 0 && n_eval == 0) {
@@ -864,6 +870,7 @@ __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restri
     const uint32_t min_len = mp.min_len, max_len = mp.max_len;
     const uint32_t pbase = (uint32_t)(t0 - w0);
     const uint64_t tail_room = ce - t0;
+    const uint32_t tail_room32 = tail_room < 0x7FFFFFFFull ? (uint32_t)tail_room : 0x7FFFFFFFu;
 
     constexpr int kSteps = ZG_LO_STEPS;
 #ifndef ZG_LO_FETCH_BATCH
@@ -926,31 +933,33 @@ __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restri
         const uint32_t n_fetch = (uint32_t)__popcll(__ballot(ft));
         if (n_fetch >= kFetchBatch || (n_fetch != 0 && n_head == 0)) {
             if (ft) {
+                // take the prefetched entry before anything younger is put in flight (see k_match)
+                uint32_t ex = nxt_ent.x, ey = nxt_ent.y;
+                asm volatile("" : "+v"(ex), "+v"(ey));
                 if (has_pos && best) match_t[idx] = (best << 16) | bestd;
                 has_pos = false;
                 if (nxt_i >= n_open) {
                     ft = false;  // nothing left to claim
                 } else {
-                    const uint2 ent = nxt_ent;
-                    nxt_i = atomicAdd(&s_counter, 1u);
-                    nxt_ent = nxt_i < n_open ? open_t[nxt_i] : make_uint2(0u, 0u);
-                    idx = ent.x & 0xFFFFu;
-                    termd = ent.x >> 16;
-                    const uint32_t fd = ent.y;
-                    const uint64_t remain = tail_room - idx;
-                    const uint32_t cap = remain < (uint64_t)(max_len - 1) ? (uint32_t)remain : max_len - 1;
+                    idx = ex & 0xFFFFu;
+                    termd = ex >> 16;
+                    const uint32_t fd = ey;
+                    const uint32_t remain32 = tail_room32 - idx;
+                    const uint32_t cap = remain32 < max_len - 1 ? remain32 : max_len - 1;
                     lim = cap < 4u ? cap : 4u;
                     best = 0;
                     bestd = 0;
                     trips = 0;
                     has_pos = true;
-                    if (fd != 0 && remain > min_len && lim >= min_len) {
+                    if (fd != 0 && remain32 > min_len && lim >= min_len) {
                         po = pbase + idx;
                         so = po - fd;
                         p0 = lds_ld4(s_data, po);
                         hd = true;
                         ft = false;
                     }
+                    nxt_i = atomicAdd(&s_counter, 1u);
+                    nxt_ent = open_t[nxt_i < n_open ? nxt_i : 0u];  // unconditional load: n_open >= 1 here
                 }
             }
         } else if (n_fetch == 0 && n_head == 0) {
