@@ -311,8 +311,206 @@ hipError_t launch_histogram(const uint32_t *tokens, uint64_t n, uint32_t *freq, 
 }
 
 // ---------------------------------------------------------------------------
-// k_huffman: one wave per chunk; lane 0 runs the block builder over LDS.
+// k_huffman: one wave per chunk builds the block's code tables and header.
+// build_block_wave is build_block (zg_huff_core.h) with the wide steps spread
+// over the 64 lanes -- sorting the symbols by count (rank sort), leaf depths
+// (every leaf climbs to the root), canonical code assignment (rank among the
+// symbols of equal length), header bits (prefix sum + OR) -- and the inherently
+// serial ones (two-queue merge, run-length coding of the lengths, the 19-symbol
+// code-length code) left to lane 0.  Same results bit for bit.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// lengths of one alphabet; all lanes call it, `len` and `w` live in LDS
+__device__ void wave_huff_lengths(const uint32_t *freq, int n, int max_bits, uint8_t *len, HuffWork &w, uint32_t lane) {
+    // used symbols in ascending (count, symbol) order: the rank of a symbol is the number of used symbols below it
+    uint32_t mine = 0;
+    for (int i = (int)lane; i < n; i += 64) {
+        len[i] = 0;
+        const uint32_t f = freq[i];
+        if (f) {
+            uint32_t rank = 0;
+            for (int j = 0; j < n; j++) {
+                const uint32_t g = freq[j];
+                rank += (g != 0u) & ((g < f) | ((g == f) & (j < i)));
+            }
+            w.sorted[rank] = (uint16_t)i;
+            mine++;
+        }
+    }
+    const int m = (int)wave_sum(mine);
+    __syncthreads();
+    if (m == 0) return;
+    if (m == 1) {  // lone symbol: one bit (RFC 1951 3.2.7); the reference panics here
+        if (lane == 0) len[w.sorted[0]] = 1;
+        __syncthreads();
+        return;
+    }
+    if (lane == 0) huff_merge(freq, m, w);
+    __syncthreads();
+    const int root = 2 * m - 2;
+    uint32_t mx = 0;
+    for (int i = (int)lane; i < m; i += 64) {
+        uint32_t d = 0;
+        for (int node = i; node != root; node = w.parent[node]) d++;
+        w.weight[i] = d;  // huff_limit reads the leaf depths from here
+        len[w.sorted[i]] = (uint8_t)(d > 255u ? 255u : d);
+        mx = d > mx ? d : mx;
+    }
+    mx = wave_max(mx);
+    __syncthreads();
+    if ((int)mx > max_bits) {
+        if (lane == 0) huff_limit(m, max_bits, len, w);
+        __syncthreads();
+    }
+}
+
+// canonical codes of one alphabet (huff_codes); cnt[17] and nxt[17] are LDS scratch
+__device__ void wave_huff_codes(const uint8_t *len, int n, uint32_t *tab, uint32_t *cnt, uint32_t *nxt, uint32_t lane) {
+    if (lane < 17) cnt[lane] = 0;
+    __syncthreads();
+    for (int i = (int)lane; i < n; i += 64)
+        if (len[i]) atomicAdd(&cnt[len[i]], 1u);
+    __syncthreads();
+    if (lane == 0) {
+        uint32_t code = 0;
+        nxt[0] = 0;
+        for (int bits = 1; bits <= 16; bits++) {
+            code = (code + (bits > 1 ? cnt[bits - 1] : 0u)) << 1;
+            nxt[bits] = code;
+        }
+    }
+    __syncthreads();
+    for (int i = (int)lane; i < n; i += 64) {
+        const uint32_t l = len[i];
+        uint32_t t = 0;
+        if (l) {
+            uint32_t rank = 0;  // symbols of the same length before this one
+            for (int j = 0; j < i; j++) rank += len[j] == l;
+            t = bit_reverse(nxt[l] + rank, l) | (l << 16);
+        }
+        tab[i] = t;
+    }
+    __syncthreads();
+}
+
+__device__ uint32_t build_block_wave(const uint32_t *freq_ll, const uint32_t *freq_d, int strategy, bool bfinal,
+                                     BlockTables &tab, uint32_t *hdr, uint64_t *payload_bits, HeaderWork &hw,
+                                     uint32_t *cnt, uint32_t *nxt, uint32_t *shared2, uint32_t lane) {
+    uint32_t hbits = 0;
+    if (strategy == ZG_FIXED) {  // get_zlib_fixed, src/huffman.rs:353-367
+        for (int i = (int)lane; i < 288; i += 64) hw.ll_len[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
+        if (lane < 30) hw.d_len[lane] = 5;
+        __syncthreads();
+        wave_huff_codes(hw.ll_len, 288, tab.ll, cnt, nxt, lane);
+        wave_huff_codes(hw.d_len, 30, tab.d, cnt, nxt, lane);
+        if (lane == 0) {
+            BitSink sink{hdr, 0};
+            sink.put(bfinal ? 1u : 0u, 1);
+            sink.put(1, 2);
+        }
+        hbits = 3;
+    } else {
+        wave_huff_lengths(freq_ll, 286, 15, hw.ll_len, hw.hw, lane);
+        wave_huff_lengths(freq_d, 30, 15, hw.d_len, hw.hw, lane);
+        wave_huff_codes(hw.ll_len, 286, tab.ll, cnt, nxt, lane);
+        wave_huff_codes(hw.d_len, 30, tab.d, cnt, nxt, lane);
+        // get_codelengths, src/compress.rs:376-407
+        uint32_t lm = 257, dm = 0, dany = 0;
+        for (int i = 258 + (int)lane; i < 286; i += 64)
+            if (hw.ll_len[i]) lm = (uint32_t)i;
+        if (lane < 30 && hw.d_len[lane]) {
+            dm = lane;
+            dany = 1;
+        }
+        const int lmax = (int)wave_max(lm);
+        const int dmax = wave_max(dany) ? (int)wave_max(dm) : 1;
+        const int nl = lmax + 1, nd = dmax + 1;
+        if (lane < 19) hw.cl_freq[lane] = 0;
+        if (lane == 0) {
+            int nr = rle_lengths(hw.ll_len, nl, hw.rsym, hw.rextra, 0);  // the two vectors are coded separately
+            nr = rle_lengths(hw.d_len, nd, hw.rsym, hw.rextra, nr);
+            shared2[0] = (uint32_t)nr;
+        }
+        __syncthreads();
+        const int nr = (int)shared2[0];
+        for (int i = (int)lane; i < nr; i += 64) atomicAdd(&hw.cl_freq[hw.rsym[i]], 1u);
+        __syncthreads();
+        if (lane == 0) {
+            huff_lengths(hw.cl_freq, 19, 7, hw.cl_len, hw.hw);  // get_code_tree
+            huff_codes(hw.cl_len, 19, hw.cl_tab);
+            const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            int nh = 19;  // get_hcodes: trailing zeros trimmed
+            while (nh > 4 && hw.cl_len[order[nh - 1]] == 0) nh--;
+            BitSink sink{hdr, 0};
+            sink.put(bfinal ? 1u : 0u, 1);
+            sink.put(2, 2);
+            sink.put((uint32_t)(nl - 257), 5);
+            sink.put((uint32_t)(nd - 1), 5);
+            sink.put((uint32_t)(nh - 4), 4);
+            for (int i = 0; i < nh; i++) sink.put(hw.cl_len[order[i]], 3);
+            shared2[1] = sink.nbits;
+        }
+        __syncthreads();
+        // the run-length items: every lane codes one, a running prefix sum places them
+        uint32_t at = shared2[1];
+        for (int i0 = 0; i0 < nr; i0 += 64) {
+            const int i = i0 + (int)lane;
+            uint32_t val = 0, nb = 0;
+            if (i < nr) {
+                const uint32_t sy = hw.rsym[i], t = hw.cl_tab[sy];
+                val = t & 0xFFFFu;
+                nb = t >> 16;
+                if (sy == 16) {
+                    val |= ((uint32_t)hw.rextra[i] - 3u) << nb;
+                    nb += 2;
+                } else if (sy == 17) {
+                    val |= ((uint32_t)hw.rextra[i] - 3u) << nb;
+                    nb += 3;
+                } else if (sy == 18) {
+                    val |= ((uint32_t)hw.rextra[i] - 11u) << nb;
+                    nb += 7;
+                }
+            }
+            uint32_t incl = nb;  // inclusive scan over the wave
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off);
+                if ((int)lane >= off) incl += o;
+            }
+            if (nb) {
+                const uint32_t pos = at + incl - nb, wd = pos >> 5, sh = pos & 31u;
+                atomicOr(&hdr[wd], val << sh);
+                if (sh + nb > 32) atomicOr(&hdr[wd + 1], val >> (32u - sh));
+            }
+            at += __shfl(incl, 63);
+        }
+        hbits = at;
+        __syncthreads();
+    }
+    // bits of all units plus the end-of-block symbol
+    uint64_t bits = 0;
+    for (int i = (int)lane; i < 286; i += 64) {
+        const uint32_t f = freq_ll[i];
+        if (!f) continue;
+        const uint32_t extra = i > 256 ? length_extra_bits((uint32_t)i - 257u) : 0u;
+        bits += (uint64_t)f * ((tab.ll[i] >> 16) + extra);
+    }
+    if (lane < 30 && freq_d[lane]) bits += (uint64_t)freq_d[lane] * ((tab.d[lane] >> 16) + dist_extra_bits(lane));
+    for (int off = 32; off > 0; off >>= 1) bits += __shfl_xor(bits, off);
+    *payload_bits = bits;
+    return hbits;
+}
+
 __global__ __launch_bounds__(64) void k_huffman(uint32_t n_chunks, int strategy, const uint32_t *__restrict__ freq,
                                                  int64_t final_chunk, uint32_t *__restrict__ tab,
                                                  uint32_t *__restrict__ hdr, uint32_t *__restrict__ hdr_bits,
@@ -321,8 +519,7 @@ __global__ __launch_bounds__(64) void k_huffman(uint32_t n_chunks, int strategy,
     __shared__ BlockTables s_tab;
     __shared__ uint32_t s_hdr[kHdrWords];
     __shared__ HeaderWork s_work;
-    __shared__ uint32_t s_hbits;
-    __shared__ uint64_t s_payload;
+    __shared__ uint32_t s_cnt[17], s_nxt[17], s_misc[2];
 
     const uint32_t c = blockIdx.x;
     if (c >= n_chunks) return;
@@ -330,21 +527,19 @@ __global__ __launch_bounds__(64) void k_huffman(uint32_t n_chunks, int strategy,
     for (uint32_t i = lane; i < kTabStride; i += 64) s_freq[i] = freq[(uint64_t)c * kTabStride + i];
     for (uint32_t i = lane; i < kHdrWords; i += 64) s_hdr[i] = 0;
     __syncthreads();
-    if (lane == 0) {
-        if (s_freq[256] == 0) s_freq[256] = 1;  // "ensure terminating character is encoded", src/huffman.rs:264
-        uint64_t payload = 0;
-        s_hbits = build_block(s_freq, s_freq + kDOff, strategy, (int64_t)c == final_chunk || final_chunk == kAllFinal, s_tab, s_hdr,
-                              &payload,
-                              s_work);
-        s_payload = payload;
-    }
+    if (lane == 0 && s_freq[256] == 0) s_freq[256] = 1;  // "ensure terminating character is encoded", src/huffman.rs:264
+    __syncthreads();
+    uint64_t payload = 0;
+    const uint32_t hbits =
+        build_block_wave(s_freq, s_freq + kDOff, strategy, (int64_t)c == final_chunk || final_chunk == kAllFinal, s_tab,
+                         s_hdr, &payload, s_work, s_cnt, s_nxt, s_misc, lane);
     __syncthreads();
     for (uint32_t i = lane; i < kHuffMaxSyms; i += 64) tab[(uint64_t)c * kTabStride + i] = s_tab.ll[i];
     if (lane < 32) tab[(uint64_t)c * kTabStride + kDOff + lane] = s_tab.d[lane];
     for (uint32_t i = lane; i < kHdrWords; i += 64) hdr[(uint64_t)c * kHdrWords + i] = s_hdr[i];
     if (lane == 0) {
-        hdr_bits[c] = s_hbits;
-        block_bits[c] = (uint64_t)s_hbits + s_payload;
+        hdr_bits[c] = hbits;
+        block_bits[c] = (uint64_t)hbits + payload;
     }
 }
 

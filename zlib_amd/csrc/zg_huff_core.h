@@ -72,18 +72,17 @@ struct HuffWork {  // scratch for one alphabet (fits LDS: ~4.7 KiB)
     uint16_t num[40];                    // codes per length
 };
 
-// Code lengths (0 = unused) for `n` symbols with counts `freq`, limited to max_bits.
-ZG_HD inline void huff_lengths(const uint32_t *freq, int n, int max_bits, uint8_t *len, HuffWork &w) {
+// Code lengths (0 = unused) for `n` symbols with counts `freq`, limited to max_bits, in four steps that the
+// device code also uses one by one (it runs the first and third with all lanes of a wave).
+
+// step 1: used symbols in ascending (count, symbol) order -> w.sorted[0..m); clears len[]
+ZG_HD inline int huff_sort(const uint32_t *freq, int n, uint8_t *len, HuffWork &w) {
     int m = 0;
     for (int i = 0; i < n; i++) {
         len[i] = 0;
         if (freq[i]) w.sorted[m++] = (uint16_t)i;
     }
-    if (m == 0) return;
-    if (m == 1) {  // lone symbol: one bit (RFC 1951 3.2.7); the reference panics here
-        len[w.sorted[0]] = 1;
-        return;
-    }
+    if (m < 2) return m;
     // heap sort by (count, symbol); symbols are already ascending so equal counts stay ordered by key
     auto less = [&](uint16_t a, uint16_t b) { return freq[a] != freq[b] ? freq[a] < freq[b] : a < b; };
     for (int start = m / 2 - 1; start >= 0; start--) {
@@ -115,32 +114,48 @@ ZG_HD inline void huff_lengths(const uint32_t *freq, int n, int max_bits, uint8_
             root = child;
         }
     }
-    // two-queue Huffman: leaves 0..m-1 (sorted), internal nodes m..2m-2 in creation order
+    return m;
+}
+
+// step 2 (m >= 2): two-queue Huffman over the sorted leaves 0..m-1; internal nodes m..2m-2 in creation order.
+// The heads of both queues are kept in locals so that an iteration does not wait on memory it just wrote.
+ZG_HD inline void huff_merge(const uint32_t *freq, int m, HuffWork &w) {
     for (int i = 0; i < m; i++) w.weight[i] = freq[w.sorted[i]];
     int li = 0, ii = m, ni = m;
+    uint32_t lw = w.weight[0];  // weight of the next leaf (valid while li < m)
+    uint32_t iw = 0;            // weight of the next internal node (valid while ii < ni)
     for (int k = 0; k < m - 1; k++) {
         int pick[2];
+        uint32_t sum = 0;
         for (int j = 0; j < 2; j++) {
-            const bool leaf = li < m && (ii >= ni || w.weight[li] <= w.weight[ii]);  // leaf wins ties
-            pick[j] = leaf ? li++ : ii++;
+            const bool leaf = li < m && (ii >= ni || lw <= iw);  // leaf wins ties
+            if (leaf) {
+                pick[j] = li++;
+                sum += lw;
+                if (li < m) lw = w.weight[li];
+            } else {
+                pick[j] = ii++;
+                sum += iw;
+                if (ii < ni) iw = w.weight[ii];
+            }
         }
-        w.weight[ni] = w.weight[pick[0]] + w.weight[pick[1]];
+        w.weight[ni] = sum;
+        if (ii == ni) iw = sum;  // the queue of internal nodes was empty: the new node is its head
         w.parent[pick[0]] = (uint16_t)ni;
         w.parent[pick[1]] = (uint16_t)ni;
         ni++;
     }
+}
+
+// step 3: depth of every node top-down (parents have larger indices), reusing weight[] for the depth
+ZG_HD inline void huff_depths(int m, HuffWork &w) {
     const int root = 2 * m - 2;
-    // depth of internal nodes top-down (parents have larger indices), reusing weight[] for depth
     w.weight[root] = 0;
     for (int i = root - 1; i >= 0; i--) w.weight[i] = w.weight[w.parent[i]] + 1;
-    int mx = 0;
-    for (int i = 0; i < m; i++) {
-        const int d = (int)w.weight[i];
-        len[w.sorted[i]] = (uint8_t)(d > 255 ? 255 : d);
-        if (d > mx) mx = d;
-    }
-    if (mx <= max_bits) return;
-    // length limiting by count rebalancing
+}
+
+// step 4: lengths from the leaf depths in w.weight[0..m); count rebalancing when the deepest exceeds max_bits
+ZG_HD inline void huff_limit(int m, int max_bits, uint8_t *len, HuffWork &w) {
     for (int i = 0; i <= max_bits; i++) w.num[i] = 0;
     for (int i = 0; i < m; i++) {
         const int d = (int)w.weight[i];
@@ -161,6 +176,24 @@ ZG_HD inline void huff_lengths(const uint32_t *freq, int n, int max_bits, uint8_
     int j = 0;
     for (int bits = max_bits; bits >= 1; bits--)
         for (int c = 0; c < (int)w.num[bits]; c++) len[w.sorted[j++]] = (uint8_t)bits;
+}
+
+ZG_HD inline void huff_lengths(const uint32_t *freq, int n, int max_bits, uint8_t *len, HuffWork &w) {
+    const int m = huff_sort(freq, n, len, w);
+    if (m == 0) return;
+    if (m == 1) {  // lone symbol: one bit (RFC 1951 3.2.7); the reference panics here
+        len[w.sorted[0]] = 1;
+        return;
+    }
+    huff_merge(freq, m, w);
+    huff_depths(m, w);
+    int mx = 0;
+    for (int i = 0; i < m; i++) {
+        const int d = (int)w.weight[i];
+        len[w.sorted[i]] = (uint8_t)(d > 255 ? 255 : d);
+        if (d > mx) mx = d;
+    }
+    if (mx > max_bits) huff_limit(m, max_bits, len, w);
 }
 
 // Canonical codes, bit-reversed (LSB-first), packed as code | len << 16.

@@ -884,17 +884,7 @@ __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restri
     uint32_t nxt_i = atomicAdd(&s_counter, 1u);
     uint2 nxt_ent = nxt_i < n_open ? open_t[nxt_i] : make_uint2(0u, 0u);
 
-#ifdef ZG_DEBUG_SPIN
-    uint32_t spin = 0;
-#endif
     for (;;) {
-#ifdef ZG_DEBUG_SPIN
-        if (++spin > 3000000u) {
-            printf("A spin blk %u tid %u hd %d ft %d idx %u so %u po %u lim %u trips %u nxt_i %u n_open %u\n", blockIdx.x, tid,
-                   (int)hd, (int)ft, idx, so, po, lim, trips, nxt_i, n_open);
-            break;
-        }
-#endif
 #pragma unroll
         for (int step = 0; step < kSteps; step++) {
             const uint32_t d = po - so;
@@ -969,12 +959,8 @@ __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restri
     __syncthreads();
 
     // parked walks, dealt round-robin to the waves
-#ifdef ZG_DEBUG_NO_B
-    const uint32_t n_parked = 0;
-#else
     const uint32_t n_raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_nparked);
     const uint32_t n_parked = n_raw < G::parked ? n_raw : G::parked;
-#endif
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     for (uint32_t e = wave; e < n_parked; e += G::threads / 64) {
         const uint32_t e0 = s_park[e * 3 + 0], e1 = s_park[e * 3 + 1], e2 = s_park[e * 3 + 2];
@@ -985,19 +971,7 @@ __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restri
         const uint32_t s_hi = ppo - excl;                           // one past the last candidate
         const uint32_t pp0 = lds_ld4(s_data, ppo);
         uint32_t first4 = 0xFFFFFFFFu, first3 = 0xFFFFFFFFu;        // lowest candidates agreeing in 4 / 3 bytes
-#ifdef ZG_DEBUG_SPIN
-        if (lane == 0 && (s_hi - s_lo) > 70000u) printf("B range blk %u e %u s_lo %u s_hi %u ppo %u excl %u n_parked %u\n", blockIdx.x, e, s_lo, s_hi, ppo, excl, n_parked);
-#endif
-#ifdef ZG_DEBUG_SPIN
-        uint32_t it = 0;
-#endif
         for (uint32_t b0 = s_lo; b0 < s_hi; b0 += 256) {
-#ifdef ZG_DEBUG_SPIN
-            if (++it > 300u) {
-                if (lane == 0) printf("B spin blk %u e %u s_lo %u s_hi %u ppo %u excl %u e0 %x e1 %x e2 %x n_parked %u\n", blockIdx.x, e, s_lo, s_hi, ppo, excl, e0, e1, e2, n_parked);
-                break;
-            }
-#endif
             const uint32_t b = b0 + lane * 4;
             const uint32_t wa = lds_ld4(s_data, b), wb = lds_ld4(s_data, b + 4);
             uint32_t h4 = 0xFFFFFFFFu, h3 = 0xFFFFFFFFu;
