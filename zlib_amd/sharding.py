@@ -87,20 +87,32 @@ def compress_sharded(engine, dist, torch, rank: int, world: int, device, final=N
     nb = engine.finish(bases[rank], first, last, adler)
     total_bytes = (end_bit + 7) // 8 + 4
     out = engine.out
+    # payload exchange: every rank's bytes go to rank 0 in one grouped batch of point-to-point operations (all
+    # peers in flight together, one hop each); the first byte of a rank travels apart because rank 0 may have
+    # to OR it into a byte the previous rank also wrote
     if first:
         final[:nb].copy_(out[:nb])
+        edges = scratch.setdefault("edges", torch.zeros(max(1, world), dtype=torch.uint8, device=device))
+        ops, spans = [], []
         for r in range(1, world):
             off = bases[r] // 8
             stop = total_bytes if r == world - 1 else (bases[r + 1] + 7) // 8
-            dist.recv(edge, src=r)
-            if bases[r] % 8:
-                final[off] |= edge[0]  # the byte two neighbouring ranks share
-            else:
-                final[off] = edge[0]
+            spans.append((r, off))
+            ops.append(dist.P2POp(dist.irecv, edges[r:r + 1], r))
             if stop - off > 1:
-                dist.recv(final[off + 1:stop], src=r)
+                ops.append(dist.P2POp(dist.irecv, final[off + 1:stop], r))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for r, off in spans:  # in rank order: a rank's first byte lands before the next rank's tail is merged
+            if bases[r] % 8:
+                final[off] |= edges[r]  # the byte two neighbouring ranks share
+            else:
+                final[off] = edges[r]
     else:
-        dist.send(out[0:1].contiguous(), dst=0)
+        ops = [dist.P2POp(dist.isend, out[0:1], 0)]
         if nb > 1:
-            dist.send(out[1:nb], dst=0)
+            ops.append(dist.P2POp(dist.isend, out[1:nb], 0))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     return total_bytes
