@@ -29,7 +29,7 @@
 #include <type_traits>
 
 #ifndef ZG_MATCH_STEPS
-#define ZG_MATCH_STEPS 8
+#define ZG_MATCH_STEPS 12
 #endif
 #ifndef ZG_LO_STEPS
 #define ZG_LO_STEPS 8
@@ -189,23 +189,25 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t *__restrict__ data, 
     }
 }
 
-// k_index_d: the fast variant, one wave per segment, three small LDS tables and no walking.
+// k_index_d: the fast variant, one wave per segment, two small LDS tables and no walking.
 //   head[h]  newest member so far.  One ds_wrxchg on it hands every lane the member inserted just before
 //            it, lanes of the same batch included, PROVIDED the LDS serialises same-address lanes of one
 //            instruction in ascending lane order.  gfx950 does (probed over 6.5*10^8 colliding exchanges,
 //            tools/probe/probe_exch.hip); the kernel still checks every returned value (a member handed out
 //            of order is not below the lane's own position) and raises bit 1 of *status, upon which the
 //            host redoes the call with k_index.
-//   old[h]   newest member among positions at least window + 1 behind the current batch: the same
-//            positions, inserted a second time with a lag of window + 64 * kIdxGroup.
-//   start[h] newest member that has no predecessor within the window (a chain start).
-// For position q: if old[h] is at or after start[h], the chain runs unbroken from old[h] up to q, so the
-// farthest in-window member is reached from old[h] by following forward links (one, or a few when the
-// batch lag leaves members between old[h] and the window's edge); otherwise the chain restarts at
-// start[h], which then is the farthest member itself.  The kernel stores that entry distance (possibly
-// beyond the window, clipped at 65535) in far[]; k_far_fix follows the links afterwards.
-// The warm-up before a segment is 2 * window + 64 * kIdxGroup positions: enough for every old[] entry that
-// can matter.
+//   entry[h] the newest position among (a) the members at least window + 1 behind the current group -- the
+//            same positions, inserted a second time with a lag of window + 64 * kIdxGroup -- and (b) the
+//            members that have no predecessor within the window (chain starts).  Both are kept with one
+//            atomic max.
+// For position q the chain runs unbroken from entry[h] up to q: if a chain start is the newer of the two it is
+// the farthest in-window member itself (or lies at most a group's span outside the window); otherwise no
+// chain start follows the lagging member, and the farthest in-window member is reached from it by following
+// forward links (one, or a few when the lag leaves members between it and the window's edge).  The kernel
+// stores that entry distance (possibly beyond the window, clipped at 65535) in far[]; k_far_fix follows the
+// links afterwards.
+// The warm-up before a segment is 2 * window + 64 * kIdxGroup positions: enough for every lagging entry
+// that can matter.
 #ifndef ZG_IDX_SEG_KB
 #define ZG_IDX_SEG_KB 192
 #endif
@@ -217,7 +219,7 @@ constexpr uint32_t kIdxGroup = ZG_IDX_GROUP;        // batches of 64 positions h
 constexpr uint32_t kIdxLagPad = 64 * kIdxGroup;
 
 template <int K>
-__device__ __forceinline__ void index_d_segment(uint32_t *s_head, uint32_t *s_old, uint32_t *s_start, uint32_t seg,
+__device__ __forceinline__ void index_d_segment(uint32_t *s_head, uint32_t *s_entry, uint32_t seg,
                                                 const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
                                                 uint64_t r1, uint64_t far_lo, uint32_t window,
                                                 uint16_t *__restrict__ far, uint16_t *__restrict__ next,
@@ -233,8 +235,7 @@ __device__ __forceinline__ void index_d_segment(uint32_t *s_head, uint32_t *s_ol
 
     for (uint32_t i = lane; i < kIdxBuckets; i += 64) {
         s_head[i] = 0;
-        s_old[i] = 0;
-        s_start[i] = 0;
+        s_entry[i] = 0;
     }
     __syncthreads();
 
@@ -270,9 +271,9 @@ __device__ __forceinline__ void index_d_segment(uint32_t *s_head, uint32_t *s_ol
     };
 
     // Positions are taken in groups of kIdxGroup batches.  The three steps of a group (insert the lagging
-    // positions and exchange the heads; mark chain starts; read old[] and start[]) are issued for all its
+    // positions and exchange the heads; mark chain starts; read entry[]) are issued for all its
     // batches back to back, so that the wave waits for the LDS twice per group instead of twice per batch.
-    // Within a group this is safe: the lag keeps every old[] entry behind the window of every lane of the
+    // Within a group this is safe: the lag keeps every lagging entry behind the window of every lane of the
     // group, and a chain start cannot share its bucket with a lane less than a window before it.
     RawKey<K> cur_m[kIdxGroup], cur_r[kIdxGroup], nxt_m[kIdxGroup], nxt_r[kIdxGroup];
     // isolated slots: a link may not reach below the first byte of the position's slot.  rel = offset of this
@@ -294,7 +295,7 @@ __device__ __forceinline__ void index_d_segment(uint32_t *s_head, uint32_t *s_ol
             valid[k] = full || (q < q_end && q + K <= n_rel);
             h[k] = hash_of(cur_m[k], q, full);
             const uint32_t hr = hash_of(cur_r[k], q - lag, true);  // a lagging position is never near the end
-            if (q >= lag) atomicMax(&s_old[hr], q - lag + 1u);
+            if (q >= lag) atomicMax(&s_entry[hr], q - lag + 1u);
         }
 #pragma unroll
         for (int k = 0; k < (int)kIdxGroup; k++) {
@@ -314,21 +315,18 @@ __device__ __forceinline__ void index_d_segment(uint32_t *s_head, uint32_t *s_ol
                 reach = r < window ? r : window;
             }
             linked[k] = old1[k] != 0u && (q + 1u - old1[k]) <= reach;
-            if (valid[k] && !linked[k]) atomicMax(&s_start[h[k]], q + 1u);
+            if (valid[k] && !linked[k]) atomicMax(&s_entry[h[k]], q + 1u);
         }
         __builtin_amdgcn_wave_barrier();  // the LDS runs one wave's accesses in program order
-        uint32_t e1[kIdxGroup], c1[kIdxGroup];
+        uint32_t e1[kIdxGroup];
 #pragma unroll
-        for (int k = 0; k < (int)kIdxGroup; k++) {
-            e1[k] = s_old[h[k]];
-            c1[k] = s_start[h[k]];
-        }
+        for (int k = 0; k < (int)kIdxGroup; k++) e1[k] = s_entry[h[k]];
 #pragma unroll
         for (int k = 0; k < (int)kIdxGroup; k++) {
             const uint32_t q = qg + (uint32_t)k * 64 + lane;
             uint32_t dist = 0;
             if (valid[k]) {
-                dist = (e1[k] != 0u && e1[k] >= c1[k]) ? q + 1u - e1[k] : q + 1u - c1[k];
+                dist = q + 1u - e1[k];  // entry[h] >= 1 here: the bucket's first member was a chain start
                 if (q >= q_main && linked[k] && old1[k] > base_rel) next_seg[old1[k] - 1u] = (uint16_t)(q + 1u - old1[k]);
             }
             if ((full || q < q_end) && q >= q_far) far_seg[q] = (uint16_t)(dist < 65535u ? dist : 65535u);
@@ -367,17 +365,16 @@ __global__ __launch_bounds__(64) void k_index_d(const uint8_t *__restrict__ data
                                                  uint16_t *__restrict__ far_b, uint16_t *__restrict__ next_b,
                                                  uint64_t base, uint32_t *status, uint64_t iso_first,
                                                  uint32_t iso_bytes) {
-    __shared__ uint32_t s_head[kIdxBuckets];   // position + 1, 0 = empty (all three)
-    __shared__ uint32_t s_old[kIdxBuckets];
-    __shared__ uint32_t s_start[kIdxBuckets];
+    __shared__ uint32_t s_head[kIdxBuckets];   // position + 1, 0 = empty (both)
+    __shared__ uint32_t s_entry[kIdxBuckets];
     const int key = blockIdx.y == 0 ? key_a : key_b;
     uint16_t *far = blockIdx.y == 0 ? far_a : far_b;
     uint16_t *next = blockIdx.y == 0 ? next_a : next_b;
     if (key == 5)
-        index_d_segment<5>(s_head, s_old, s_start, blockIdx.x, data, n_view, r0, r1, far_lo, window, far, next, base,
+        index_d_segment<5>(s_head, s_entry, blockIdx.x, data, n_view, r0, r1, far_lo, window, far, next, base,
                            status, iso_first, iso_bytes);
     else
-        index_d_segment<3>(s_head, s_old, s_start, blockIdx.x, data, n_view, r0, r1, far_lo, window, far, next, base,
+        index_d_segment<3>(s_head, s_entry, blockIdx.x, data, n_view, r0, r1, far_lo, window, far, next, base,
                            status, iso_first, iso_bytes);
 }
 
