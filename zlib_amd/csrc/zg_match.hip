@@ -567,6 +567,18 @@ __device__ __forceinline__ uint32_t lds_lcp(const uint8_t *lds, uint32_t so, uin
     return m < cap ? m : cap;
 }
 
+// Workgroups are dealt round-robin to the eight XCDs, each with an L2 of its own.  Neighbouring tiles stage
+// mostly the same window, so the block index is turned into a tile index that gives every XCD a contiguous run
+// of tiles: block b runs on XCD b % 8 and takes the (b / 8)-th tile of that XCD's run.
+__device__ __forceinline__ uint32_t xcd_tile_index(uint32_t b, uint32_t n) {
+#ifdef ZG_NO_XCD_REMAP
+    return b;
+#else
+    const uint32_t per = n >> 3, rem = n & 7u, xcd = b & 7u, slot = b >> 3;
+    return xcd * per + (xcd < rem ? xcd : rem) + slot;
+#endif
+}
+
 // copies bytes [w0, w0 + nbytes) and links [w0, w0 + nlinks) of the view into LDS
 __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ data, const uint16_t *__restrict__ next,
                                            uint64_t base, uint64_t w0, uint32_t nbytes, uint32_t nlinks,
@@ -616,13 +628,14 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     uint8_t *const s_data = s_mem;
     uint16_t *const s_next = reinterpret_cast<uint16_t *>(s_mem + G::data_lds);
 
-    const uint32_t chunk = c0 + blockIdx.x / tiles_per_chunk;
-    const uint32_t tile = blockIdx.x % tiles_per_chunk;
+    const uint32_t bid = xcd_tile_index(blockIdx.x, gridDim.x);
+    const uint32_t chunk = c0 + bid / tiles_per_chunk;
+    const uint32_t tile = bid % tiles_per_chunk;
     const uint64_t cs = first + (uint64_t)chunk * chunk_bytes;
     const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, chunk);
     const uint64_t t0 = cs + (uint64_t)tile * G::tile;
     if (t0 >= ce) {
-        if (emit_term && threadIdx.x == 0) open_cnt[blockIdx.x] = 0;
+        if (emit_term && threadIdx.x == 0) open_cnt[bid] = 0;
         return;
     }
     const uint64_t t1 = (t0 + G::tile < ce) ? t0 + G::tile : ce;
@@ -655,7 +668,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     const uint32_t pbase = (uint32_t)(t0 - w0);  // LDS offset of tile position 0
     const uint16_t *far_t = far + (t0 - base);
     const uint16_t *far_lo_t = emit_term ? far_lo + (t0 - base) : far_t;
-    uint2 *open_t = open_list + (uint64_t)blockIdx.x * G::tile;
+    uint2 *open_t = open_list + (uint64_t)bid * G::tile;
     uint32_t *match_t = match + (t0 - base);
     const uint64_t tail_room = ce - t0;  // bytes from tile position 0 to the end of the chunk
     const uint32_t tail_room32 = tail_room < 0x7FFFFFFFull ? (uint32_t)tail_room : 0x7FFFFFFFu;
@@ -806,7 +819,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     }
     if (emit_term) {
         __syncthreads();
-        if (tid == 0) open_cnt[blockIdx.x] = s_nopen;
+        if (tid == 0) open_cnt[bid] = s_nopen;
     }
 }
 
@@ -840,10 +853,11 @@ __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restri
     uint8_t *const s_data = s_mem;
     uint16_t *const s_next = reinterpret_cast<uint16_t *>(s_mem + G::data_lds);
 
-    const uint32_t n_open = open_cnt[blockIdx.x];
+    const uint32_t bid = xcd_tile_index(blockIdx.x, gridDim.x);
+    const uint32_t n_open = open_cnt[bid];
     if (n_open == 0) return;
-    const uint32_t chunk = c0 + blockIdx.x / tiles_per_chunk;
-    const uint32_t tile = blockIdx.x % tiles_per_chunk;
+    const uint32_t chunk = c0 + bid / tiles_per_chunk;
+    const uint32_t tile = bid % tiles_per_chunk;
     const uint64_t cs = first + (uint64_t)chunk * chunk_bytes;
     const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, chunk);
     const uint64_t t0 = cs + (uint64_t)tile * G::tile;
@@ -855,7 +869,7 @@ __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restri
     const uint32_t nbytes = (uint32_t)(w1 - w0);
     const uint32_t nlinks = (uint32_t)(t1 - w0);
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint2 *open_t = open_list + (uint64_t)blockIdx.x * G::tile;
+    const uint2 *open_t = open_list + (uint64_t)bid * G::tile;
     uint32_t *match_t = match + (t0 - base);
     if (tid == 0) {
         s_counter = 0;
