@@ -105,6 +105,19 @@ __device__ __forceinline__ uint32_t hash_at(const uint8_t *__restrict__ data, ui
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
+// Workgroups are dealt round-robin to the eight XCDs, each with an L2 of its own.  Neighbouring tiles (of the match
+// kernels, of the far fix-up) read mostly the same memory, so the block index is turned into a tile index that
+// gives every XCD a contiguous run of tiles: block b runs on XCD b % 8 and takes the (b / 8)-th tile of that XCD's run.
+__device__ __forceinline__ uint32_t xcd_tile_index(uint32_t b, uint32_t n) {
+#ifdef ZG_NO_XCD_REMAP
+    return b;
+#else
+    const uint32_t per = n >> 3, rem = n & 7u, xcd = b & 7u, slot = b >> 3;
+    return xcd * per + (xcd < rem ? xcd : rem) + slot;
+#endif
+}
+
+
 // k_index: the conservative variant.  One wave per segment walks positions in batches of 64, keeping per
 // bucket the newest member (head) and the farthest in-window member (tail), plus a 64 Ki-entry ring of forward
 // links; lanes of a batch that share a bucket are grouped with ballots.
@@ -380,12 +393,15 @@ __global__ __launch_bounds__(64) void k_index_d(const uint8_t *__restrict__ data
 
 // k_far_fix: turns the entry distances k_index_d left in far[] into distances of the farthest in-window member.
 // Each thread takes kFixPer positions, 256 apart, so that their dependent link reads overlap.
-constexpr uint32_t kFixPer = 4;
+#ifndef ZG_FIX_PER
+#define ZG_FIX_PER 8
+#endif
+constexpr uint32_t kFixPer = ZG_FIX_PER;
 template <int K>
 __device__ __forceinline__ void far_fix_block(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t far_lo,
                                               uint64_t r1, uint32_t window, uint16_t *__restrict__ far,
                                               const uint16_t *__restrict__ next, uint64_t base) {
-    const uint64_t p0 = far_lo + (uint64_t)blockIdx.x * (256 * kFixPer) + threadIdx.x;
+    const uint64_t p0 = far_lo + (uint64_t)xcd_tile_index(blockIdx.x, gridDim.x) * (256 * kFixPer) + threadIdx.x;
     const uint32_t d_max = 2u * window + kIdxLagPad - 1u;
     uint32_t d[kFixPer];
     bool live[kFixPer];
@@ -565,18 +581,6 @@ __device__ __forceinline__ uint32_t lds_lcp(const uint8_t *lds, uint32_t so, uin
         m += 4;
     }
     return m < cap ? m : cap;
-}
-
-// Workgroups are dealt round-robin to the eight XCDs, each with an L2 of its own.  Neighbouring tiles stage
-// mostly the same window, so the block index is turned into a tile index that gives every XCD a contiguous run
-// of tiles: block b runs on XCD b % 8 and takes the (b / 8)-th tile of that XCD's run.
-__device__ __forceinline__ uint32_t xcd_tile_index(uint32_t b, uint32_t n) {
-#ifdef ZG_NO_XCD_REMAP
-    return b;
-#else
-    const uint32_t per = n >> 3, rem = n & 7u, xcd = b & 7u, slot = b >> 3;
-    return xcd * per + (xcd < rem ? xcd : rem) + slot;
-#endif
 }
 
 // copies bytes [w0, w0 + nbytes) and links [w0, w0 + nlinks) of the view into LDS
