@@ -37,7 +37,8 @@ enum {
     ZG_ERR_NOMEM = -4,       /* host or device allocation failed                      */
     ZG_ERR_CAPACITY = -5,    /* caller-provided output buffer too small               */
     ZG_ERR_UNSUPPORTED = -6, /* parameters outside what the device path implements    */
-    ZG_ERR_INTERNAL = -7     /* a device-side consistency check failed                */
+    ZG_ERR_INTERNAL = -7,    /* a device-side consistency check failed                */
+    ZG_ERR_DATA = -8         /* decompress: invalid or corrupt zlib stream            */
 };
 
 /* Strategy: src/compress.rs:28-34 (same order). */
@@ -98,6 +99,25 @@ size_t zg_compress_batch_bound(size_t stride, size_t n_records, int strategy);
 int zg_compress_batch_device(zg_ctx *ctx, const void *d_in, size_t stride, const uint32_t *d_len,
                              size_t n_records, int strategy, void *d_out, size_t out_cap,
                              uint64_t *d_out_offsets, size_t *out_bytes);
+
+/* ---- zlib::decompress(&[u8]) -> Result<Vec<u8>, String>   (src/decompress.rs:34-88) ----
+ * Inflate on the device.  Err(String) of the reference (bad CM / CINFO / FCHECK /
+ * FDICT, block type 3, Adler-32 mismatch) is ZG_ERR_DATA with the reference's
+ * message in zg_last_error; corrupt bodies, where the reference panics, likewise.
+ * One stream is decoded by one lane (DEFLATE decoding is serial), so a single
+ * large stream is slow; the batch forms decode all streams in parallel.
+ * *out (and *out_offsets, n_streams + 1 entries) are malloc'ed: zg_free. */
+int zg_decompress(zg_ctx *ctx, const uint8_t *in, size_t n, uint8_t **out, size_t *out_n);
+int zg_decompress_batch(zg_ctx *ctx, const uint8_t *in, const size_t *offsets, size_t n_streams,
+                        uint8_t **out, size_t **out_offsets);
+/* Device memory: stream i is d_in[d_in_offsets[i] .. d_in_offsets[i+1]); its output goes
+ * to the slot d_out[d_out_offsets[i] .. d_out_offsets[i+1]); d_out_len[i] receives the
+ * number of bytes, d_status[i] 0 or a non-zero reason (11 = slot too small).  With
+ * d_out == NULL only the lengths are computed (no Adler-32 check).  The call itself
+ * returns ZG_OK unless the launch failed: look at d_status. */
+int zg_decompress_batch_device(zg_ctx *ctx, const void *d_in, const uint64_t *d_in_offsets, size_t n_streams,
+                               void *d_out, const uint64_t *d_out_offsets, uint64_t *d_out_len,
+                               uint32_t *d_status);
 
 /* ---- sharded compress: one rank of a multi-GPU job ----
  * A rank owns `n` input bytes (a whole number of chunks unless it is the last

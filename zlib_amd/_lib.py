@@ -13,13 +13,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzlib_amd.so")
 
 OK = 0
-ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_INTERNAL = -1, -2, -3, -4, -5, -6, -7
+ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_INTERNAL, ERR_DATA = -1, -2, -3, -4, -5, -6, -7, -8
 
 #: every symbol include/zlib_amd.h declares
 SYMBOLS = [
     "zg_init", "zg_destroy", "zg_strerror", "zg_last_error", "zg_free", "zg_compress", "zg_compress_bound",
     "zg_compress_device", "zg_compress_batch", "zg_compress_batch_bound", "zg_compress_batch_device",
-    "zg_shard_begin", "zg_shard_finish", "zg_adler32_combine", "zg_adler32",
+    "zg_decompress", "zg_decompress_batch", "zg_decompress_batch_device", "zg_shard_begin", "zg_shard_finish", "zg_adler32_combine", "zg_adler32",
     "zg_adler32_device", "zg_lz77", "zg_huffman_from_tokens", "zg_profile_enable", "zg_profile_reset",
     "zg_profile_count", "zg_profile_get", "zg_corpus_fill",
 ]
@@ -76,6 +76,10 @@ def _declare(L):
       C.POINTER(C.POINTER(sz)))
     f("zg_compress_batch_bound", sz, sz, sz, C.c_int)
     f("zg_compress_batch_device", C.c_int, vp, vp, sz, vp, sz, C.c_int, vp, sz, vp, C.POINTER(sz))
+    f("zg_decompress", C.c_int, vp, C.c_char_p, sz, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz))
+    f("zg_decompress_batch", C.c_int, vp, C.c_char_p, C.POINTER(sz), sz, C.POINTER(C.POINTER(C.c_uint8)),
+      C.POINTER(C.POINTER(sz)))
+    f("zg_decompress_batch_device", C.c_int, vp, vp, vp, sz, vp, vp, vp, vp)
     f("zg_shard_begin", C.c_int, vp, vp, sz, sz, C.c_int, C.POINTER(Opts), C.c_int, C.POINTER(ShardInfo))
     f("zg_shard_finish", C.c_int, vp, C.c_uint64, C.c_int, C.c_int, C.c_uint32, vp, sz, C.POINTER(sz))
     f("zg_adler32_combine", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64)

@@ -93,7 +93,7 @@ def default_context() -> Context:
 def _check(rc: int, ctx: Optional[Context] = None):
     if rc:
         detail = ""
-        if rc == _lib.ERR_HIP and ctx is not None:
+        if rc in (_lib.ERR_HIP, _lib.ERR_DATA, _lib.ERR_CAPACITY) and ctx is not None:
             detail = _lib.lib().zg_last_error(ctx.handle).decode()
         raise ZgError(rc, detail)
 
@@ -149,6 +149,38 @@ def compress_batch(records: Sequence[bytes], strategy: Strategy = Strategy.Dynam
         total = out_offs[len(records)]
         whole = C.string_at(out, total)
         return [whole[out_offs[i]:out_offs[i + 1]] for i in range(len(records))]
+    finally:
+        _lib.lib().zg_free(out)
+        _lib.lib().zg_free(out_offs)
+
+
+def decompress(data: bytes, *, ctx: Optional[Context] = None) -> bytes:
+    """zlib::decompress(&data): Ok(bytes) or ZgError (ZG_ERR_DATA, the reference's Err text as the message)."""
+    ctx = ctx or default_context()
+    data = bytes(data)
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    _check(_lib.lib().zg_decompress(ctx.handle, data, len(data), C.byref(out), C.byref(n)), ctx)
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        _lib.lib().zg_free(out)
+
+
+def decompress_batch(streams: Sequence[bytes], *, ctx: Optional[Context] = None) -> List[bytes]:
+    """[zlib::decompress(s) for s in streams], all streams in flight on the GPU at once."""
+    ctx = ctx or default_context()
+    blob = b"".join(bytes(s) for s in streams)
+    offs = (C.c_size_t * (len(streams) + 1))()
+    pos = 0
+    for i, s in enumerate(streams):
+        offs[i] = pos
+        pos += len(s)
+    offs[len(streams)] = pos
+    out, out_offs = C.POINTER(C.c_uint8)(), C.POINTER(C.c_size_t)()
+    _check(_lib.lib().zg_decompress_batch(ctx.handle, blob, offs, len(streams), C.byref(out), C.byref(out_offs)), ctx)
+    try:
+        whole = C.string_at(out, out_offs[len(streams)])
+        return [whole[out_offs[i]:out_offs[i + 1]] for i in range(len(streams))]
     finally:
         _lib.lib().zg_free(out)
         _lib.lib().zg_free(out_offs)

@@ -42,9 +42,9 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
-enum KernelId { K_INDEX, K_MATCH, K_MATCH_LO, K_PARSE, K_HUFFMAN, K_TILEBITS, K_OFFSETS, K_ENCODE, K_ADLER, K_STORED, K_MISC, K_COUNT };
+enum KernelId { K_INDEX, K_MATCH, K_MATCH_LO, K_PARSE, K_HUFFMAN, K_TILEBITS, K_OFFSETS, K_ENCODE, K_ADLER, K_STORED, K_INFLATE, K_MISC, K_COUNT };
 const char *const kKernelNames[K_COUNT] = {"k_index", "k_match", "k_match_lo", "k_parse", "k_huffman", "k_tile_bits",
-                                           "k_offsets", "k_encode", "k_adler", "k_stored", "misc"};
+                                           "k_offsets", "k_encode", "k_adler", "k_stored", "k_inflate", "misc"};
 
 // device scalars
 struct Scalars {
@@ -63,7 +63,7 @@ struct zg_ctx {
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::string err;
-    DevBuf far, next, far3, next3, open_list, open_cnt, rec_len, rec_off, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
+    DevBuf far, next, far3, next3, open_list, open_cnt, rec_len, rec_off, inf_off, inf_len, inf_status, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
         scalars, stage_in, stage_out, misc, flag, sub_exit, sub_exit2, merged, tile_cnt, adler_blk;
     // shard state kept between zg_shard_begin and zg_shard_finish
     bool shard_active = false;
@@ -435,7 +435,7 @@ void zg_destroy(zg_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf *bufs[] = {&c->far, &c->next, &c->far3, &c->next3, &c->open_list, &c->open_cnt, &c->rec_len, &c->rec_off, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
+    DevBuf *bufs[] = {&c->far, &c->next, &c->far3, &c->next3, &c->open_list, &c->open_cnt, &c->rec_len, &c->rec_off, &c->inf_off, &c->inf_len, &c->inf_status, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
                       &c->block_bits, &c->bit_off, &c->tile_bits, &c->adler_part, &c->scalars, &c->stage_in,
                       &c->stage_out, &c->misc, &c->flag, &c->sub_exit, &c->sub_exit2, &c->merged, &c->tile_cnt,
                       &c->adler_blk};
@@ -454,6 +454,7 @@ const char *zg_strerror(int code) {
     case ZG_ERR_CAPACITY: return "output buffer too small";
     case ZG_ERR_UNSUPPORTED: return "parameters not supported by the device path";
     case ZG_ERR_INTERNAL: return "internal consistency check failed";
+    case ZG_ERR_DATA: return "invalid or corrupt zlib stream";
     default: return "unknown error";
     }
 }
@@ -658,6 +659,130 @@ int zg_compress_batch(zg_ctx *ctx, const uint8_t *in, const size_t *offsets, siz
     for (size_t i = 0; i <= n_records; i++) ho[i] = (size_t)off64[i];
     *out = h;
     *out_offsets = ho;
+    return ZG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// zlib::decompress(&[u8]) -> Result<Vec<u8>, String> (reference src/decompress.rs:34-88) on the device, for
+// one stream or many.  Err(String) becomes ZG_ERR_DATA with the reference's message in zg_last_error; so do
+// the corrupt-body cases where the reference panics.
+// ---------------------------------------------------------------------------
+namespace {
+const char *inflate_message(uint32_t st) {
+    switch (st) {
+    case INF_BAD_METHOD: return "CM is not a supported compression method";     // src/decompress.rs:44-46
+    case INF_BAD_WINDOW: return "Invalid compression info, must be < 7";        // :51-55
+    case INF_BAD_FCHECK: return "CMF + FLAGS checksum failed!";                 // :61-63
+    case INF_PRESET_DICT: return "Preset dictionaries are not supported";       // :67-69
+    case INF_BAD_BLOCK: return "Invalid block type";                            // :113
+    case INF_BAD_CHECKSUM: return "Checksum is invalid";                        // :86
+    case INF_BAD_CODES: return "invalid code lengths in a dynamic block";
+    case INF_BAD_SYMBOL: return "bits that match no code (the reference panics: Invalid decoded value)";
+    case INF_BAD_DISTANCE: return "distance reaches before the start of the output";
+    case INF_TRUNCATED: return "input ends inside the stream";
+    case INF_OVERFLOW: return "output slot too small";
+    default: return "ok";
+    }
+}
+
+// first failing stream -> ZG_ERR_DATA (or ZG_ERR_CAPACITY) with a message; st = host copy of the statuses
+int inflate_verdict(zg_ctx *c, const std::vector<uint32_t> &st) {
+    for (size_t i = 0; i < st.size(); i++)
+        if (st[i] != INF_OK) {
+            c->err = std::string(inflate_message(st[i])) + " (stream " + std::to_string(i) + ")";
+            return st[i] == INF_OVERFLOW ? ZG_ERR_CAPACITY : ZG_ERR_DATA;
+        }
+    return ZG_OK;
+}
+}  // namespace
+
+int zg_decompress_batch_device(zg_ctx *ctx, const void *d_in, const uint64_t *d_in_offsets, size_t n_streams,
+                               void *d_out, const uint64_t *d_out_offsets, uint64_t *d_out_len, uint32_t *d_status) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (!d_in_offsets || !d_out_len || !d_status || n_streams > 0xFFFFFFFFull) return ZG_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    // d_out == NULL: sizes only (no output is written, the Adler-32 is not checked)
+    LAUNCH(K_INFLATE, launch_inflate(static_cast<const uint8_t *>(d_in), d_in_offsets, (uint32_t)n_streams,
+                                     static_cast<uint8_t *>(d_out), d_out_offsets, d_out_len, d_status,
+                                     d_out == nullptr, false, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->prof) prof_collect(c);
+    return ZG_OK;
+}
+
+int zg_decompress_batch(zg_ctx *ctx, const uint8_t *in, const size_t *offsets, size_t n_streams, uint8_t **out,
+                        size_t **out_offsets) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (!out || !out_offsets || !offsets || n_streams > 0xFFFFFFFFull) return ZG_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    for (size_t i = 0; i < n_streams; i++)
+        if (offsets[i + 1] < offsets[i]) return ZG_ERR_ARG;
+    const size_t total_in = n_streams ? offsets[n_streams] - offsets[0] : 0;
+    if (total_in && !in) return ZG_ERR_ARG;
+    std::vector<uint64_t> off(n_streams + 1, 0), olen(n_streams, 0), ooff(n_streams + 1, 0);
+    std::vector<uint32_t> st(n_streams, 0);
+    for (size_t i = 0; i <= n_streams; i++) off[i] = offsets[i] - offsets[0];
+    HIPCHK(c->stage_in.ensure(total_in + 64));
+    HIPCHK(c->inf_off.ensure(2 * (n_streams + 1) * sizeof(uint64_t)));
+    HIPCHK(c->inf_len.ensure((n_streams + 1) * sizeof(uint64_t)));
+    HIPCHK(c->inf_status.ensure((n_streams + 1) * sizeof(uint32_t)));
+    uint64_t *d_off = c->inf_off.as<uint64_t>(), *d_ooff = d_off + (n_streams + 1);
+    if (total_in) HIPCHK(hipMemcpy(c->stage_in.p, in + offsets[0], total_in, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_off, off.data(), (n_streams + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    size_t total_out = 0;
+    if (n_streams) {
+        // pass 1: sizes (the output length of a stream follows from its symbols alone)
+        LAUNCH(K_INFLATE, launch_inflate(c->stage_in.as<uint8_t>(), d_off, (uint32_t)n_streams, nullptr, nullptr,
+                                         c->inf_len.as<uint64_t>(), c->inf_status.as<uint32_t>(), true, false,
+                                         c->stream));
+        HIPCHK(hipMemcpyAsync(olen.data(), c->inf_len.p, n_streams * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(st.data(), c->inf_status.p, n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        rc = inflate_verdict(c, st);
+        if (rc) return rc;
+        for (size_t i = 0; i < n_streams; i++) ooff[i + 1] = ooff[i] + olen[i];
+        total_out = (size_t)ooff[n_streams];
+        HIPCHK(c->stage_out.ensure(total_out + 64));
+        HIPCHK(hipMemcpy(d_ooff, ooff.data(), (n_streams + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        // pass 2: bytes and checksums; a wave per stream when the streams are few and long
+        const bool large = n_streams <= 4096 && total_out / n_streams >= (64u << 10);
+        LAUNCH(K_INFLATE, launch_inflate(c->stage_in.as<uint8_t>(), d_off, (uint32_t)n_streams,
+                                         c->stage_out.as<uint8_t>(), d_ooff, c->inf_len.as<uint64_t>(),
+                                         c->inf_status.as<uint32_t>(), false, large, c->stream));
+        HIPCHK(hipMemcpyAsync(st.data(), c->inf_status.p, n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->prof) prof_collect(c);
+        rc = inflate_verdict(c, st);
+        if (rc) return rc;
+    }
+    uint8_t *h = static_cast<uint8_t *>(malloc(total_out ? total_out : 1));
+    size_t *ho = static_cast<size_t *>(malloc((n_streams + 1) * sizeof(size_t)));
+    if (!h || !ho) {
+        free(h);
+        free(ho);
+        return ZG_ERR_NOMEM;
+    }
+    if (total_out) HIPCHK(hipMemcpy(h, c->stage_out.p, total_out, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i <= n_streams; i++) ho[i] = (size_t)ooff[i];
+    *out = h;
+    *out_offsets = ho;
+    return ZG_OK;
+}
+
+int zg_decompress(zg_ctx *ctx, const uint8_t *in, size_t n, uint8_t **out, size_t *out_n) {
+    if (!out || !out_n) return ZG_ERR_ARG;
+    const size_t offsets[2] = {0, n};
+    size_t *oo = nullptr;
+    const int rc = zg_decompress_batch(ctx, in, offsets, 1, out, &oo);
+    if (rc) return rc;
+    *out_n = oo[1];
+    free(oo);
     return ZG_OK;
 }
 

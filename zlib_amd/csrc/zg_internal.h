@@ -133,6 +133,26 @@ hipError_t launch_adler_fold(const uint32_t *partial, uint64_t n, uint64_t seg_b
                              uint64_t *block_part /* 3 words per 1024 segments */, uint32_t *state /* [a, b] running */,
                              hipStream_t s);
 hipError_t launch_stored(const uint8_t *data, uint64_t n, uint8_t *out, uint32_t *partial, hipStream_t s);
+// inflate: one lane per stream; stream i is in[in_off[i] .. in_off[i+1]), its output slot out[out_off[i] ..
+// out_off[i+1]); size_only counts the output bytes without writing them (and without checking the Adler-32);
+// large selects the wave-per-stream kernel (few, long streams)
+enum InflateStatus : uint32_t {
+    INF_OK = 0,
+    INF_BAD_METHOD,    // CM != 8
+    INF_BAD_WINDOW,    // CINFO > 7
+    INF_BAD_FCHECK,    // CMF/FLG checksum
+    INF_PRESET_DICT,   // FDICT set
+    INF_BAD_BLOCK,     // block type 3
+    INF_BAD_CODES,     // code lengths that describe no prefix code, or a malformed code description
+    INF_BAD_SYMBOL,    // bits that match no code, or a symbol outside the alphabet
+    INF_BAD_DISTANCE,  // a match reaching before the start of the output
+    INF_TRUNCATED,     // the input ends inside the stream
+    INF_BAD_CHECKSUM,  // Adler-32 mismatch
+    INF_OVERFLOW,      // the output slot is too small
+};
+hipError_t launch_inflate(const uint8_t *in, const uint64_t *in_off, uint32_t n_streams, uint8_t *out,
+                          const uint64_t *out_off, uint64_t *out_len, uint32_t *status, bool size_only, bool large,
+                          hipStream_t s);
 hipError_t launch_trailer(uint8_t *out, const uint64_t *total_bits, const uint32_t *adler_state,
                           uint32_t adler_override, int use_override, int write_header, int write_adler,
                           uint64_t *out_bytes, hipStream_t s);
