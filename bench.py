@@ -125,15 +125,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # ZG_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share cards)
+    backend = os.environ.get("ZG_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     # weak scaling: every GPU owns per_gpu bytes of one corpus of world * per_gpu bytes
     total = per_gpu * world
-    ctx = za.Context(local_rank)
+    ctx = za.Context(dev_index)
     start, n, halo = sharding.plan_shards(total, chunk, world)[rank]
     d_in = upload_corpus(torch, za, kind, seed, start - halo, halo + n, device)
     strategy = getattr(za.Strategy, strat_name)
