@@ -211,8 +211,10 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
               int64_t final_chunk, bool want_codes) {
     const uint64_t bs = g.first + (uint64_t)c0 * g.chunk_bytes;
     const uint64_t be = std::min<uint64_t>(g.end, g.first + (uint64_t)c1 * g.chunk_bytes);
-    const uint64_t back = index_lookback(mp.window);
+    // isolated chunks see nothing before their own first byte; others need the index a window behind them
+    const uint64_t back = g.isolated ? 0 : index_lookback(mp.window);
     const uint64_t ib0 = (bs > back ? bs - back : 0) & ~(uint64_t)15;  // scratch arrays start here
+    const uint64_t ix0 = g.isolated ? bs : ib0;                        // first indexed position
     const uint64_t span = be - ib0;
     const bool two_level = mp.min_len < 5;  // lengths 3 and 4 need the three-byte chains
     const uint64_t iso_first = g.isolated ? g.first : 0;
@@ -228,14 +230,12 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
     HIPCHK(c->tokens.ensure((be - bs) * 4 + 64));
     if (span) {
         uint32_t *status = &c->scalars.as<Scalars>()->status;
-        LAUNCH(K_MISC, hipMemsetAsync(c->next.p, 0, span * 2, c->stream));
         if (two_level) {
             const uint64_t ntiles = (uint64_t)(c1 - c0) * match_tiles_per_chunk(g);
             HIPCHK(c->open_list.ensure(ntiles * match_tile_positions(g) * sizeof(uint2)));
             HIPCHK(c->open_cnt.ensure(ntiles * sizeof(uint32_t)));
-            LAUNCH(K_MISC, hipMemsetAsync(c->next3.p, 0, span * 2, c->stream));
         }
-        LAUNCH(K_INDEX, launch_index(g.data, g.end, ib0, be, bs, mp.window, 5, c->far.as<uint16_t>(),
+        LAUNCH(K_INDEX, launch_index(g.data, g.end, ix0, be, bs, mp.window, 5, c->far.as<uint16_t>(),
                                      c->next.as<uint16_t>(), two_level ? 3 : 0, c->far3.as<uint16_t>(),
                                      c->next3.as<uint16_t>(), ib0, status, c->index_safe, iso_first, iso_bytes,
                                      c->stream));

@@ -82,9 +82,11 @@ __device__ __forceinline__ uint64_t chunk_end(uint64_t cs, uint64_t chunk_bytes,
 
 // launchers (each enqueues on `s` and returns the HIP status of the launch)
 // index of positions [r0, r1) by the hash of their first key_bytes (3 or 5) bytes; far[] for [far_lo, r1) only.
-// The arrays start at view position `base`, which must lie index_lookback(window) or more behind far_lo
-// (or at 0), and next[] must be zero on entry.
-// iso_bytes != 0: positions belong to slots of iso_bytes starting at iso_first, and chains never leave a slot.
+// Members below r0 are not seen: r0 must lie index_lookback(window) or more behind far_lo, or be the first
+// position that can matter (the start of the data; the first byte of an isolated slot).  The arrays start at
+// view position `base` <= r0.  Every next[] of [r0, r1) and far[] of [far_lo, r1) is written.
+// iso_bytes != 0: positions belong to slots of iso_bytes (a multiple of 1024) starting at iso_first, chains
+// never leave a slot, and r0 is the first byte of a slot.
 // Builds the index for key length key_a and, unless key_b is 0, a second one for key_b in the same launches.
 hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
                         uint32_t window, int key_a, uint16_t *far_a, uint16_t *next_a, int key_b, uint16_t *far_b,

@@ -43,17 +43,16 @@ namespace zg {
 //   far[p]  = p - (smallest bucket member >= p - window), 0 if none
 //   next[s] = distance from s to the next bucket member, 0 if none within window
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t hash3(uint32_t tri) { return (tri * 0x9E3779B1u) >> (32 - kIdxHashBits); }
-
+// 32-bit mix of the first K bytes; a table of 2^b buckets takes its top b bits
 template <int K>
 __device__ __forceinline__ uint32_t key_hash(uint32_t lo, uint32_t hi);
 template <>
 __device__ __forceinline__ uint32_t key_hash<3>(uint32_t lo, uint32_t) {
-    return hash3(lo & 0x00FFFFFFu);
+    return (lo & 0x00FFFFFFu) * 0x9E3779B1u;
 }
 template <>
 __device__ __forceinline__ uint32_t key_hash<5>(uint32_t lo, uint32_t hi) {
-    return (lo * 0x9E3779B1u + (hi & 0xFFu) * 0x85EBCA6Bu) >> (32 - kIdxHashBits);
+    return lo * 0x9E3779B1u + (hi & 0xFFu) * 0x85EBCA6Bu;
 }
 
 // the first K bytes at view position p (p + K <= n_view): low four in lo, the fifth in hi
@@ -68,34 +67,12 @@ __device__ __forceinline__ void load_key(const uint8_t *__restrict__ data, uint6
     hi = (K > 4) ? (uint32_t)data[p + 4] : 0u;
 }
 
-// The same without branches, so that the loads can stay in flight across loop iterations: the address is
-// clamped into the view (n_view >= 8) and the bytes are shifted into place afterwards.  The result is
-// meaningful only when p + K <= n_view.
+// eight (K = 5) or four (K = 3) bytes loaded at a position, or at the last offset of the view that allows such a
+// load (the bytes are shifted into place afterwards): loads without branches stay in flight across iterations
 template <int K>
 struct RawKey {
     uint32_t a, b;
 };
-template <int K>
-__device__ __forceinline__ RawKey<K> raw_load(const uint8_t *__restrict__ data, uint64_t p, uint64_t n_view) {
-    const uint64_t last = n_view - (K > 4 ? 8 : 4);
-    const uint64_t pc = p < last ? p : last;
-    RawKey<K> r;
-    __builtin_memcpy(&r.a, data + pc, 4);
-    r.b = 0;
-    if (K > 4) __builtin_memcpy(&r.b, data + pc + 4, 4);
-    return r;
-}
-template <int K>
-__device__ __forceinline__ uint32_t raw_hash(RawKey<K> r, uint64_t p, uint64_t n_view) {
-    const uint64_t last = n_view - (K > 4 ? 8 : 4);
-    const uint32_t sh = p < last ? 0u : ((uint32_t)(p - last) & 7u) * 8u;
-    if (K > 4) {
-        const uint64_t v = (((uint64_t)r.b << 32) | r.a) >> sh;
-        return key_hash<K>((uint32_t)v, (uint32_t)(v >> 32));
-    }
-    return key_hash<K>(r.a >> (sh & 31u), 0u);
-}
-
 template <int K>
 __device__ __forceinline__ uint32_t hash_at(const uint8_t *__restrict__ data, uint64_t p, uint64_t n_view) {
     uint32_t lo, hi;
@@ -147,7 +124,7 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t *__restrict__ data, 
         const uint64_t p = a0 + q;
         const bool inseg = q < q_end;
         const bool valid = inseg && (p + K <= n_view);
-        const uint32_t h = valid ? hash_at<K>(data, p, n_view) : 0u;
+        const uint32_t h = valid ? hash_at<K>(data, p, n_view) >> (32 - kIdxHashBits) : 0u;
         // lanes of this batch that share my bucket
         uint64_t mygrp = 0;
         uint64_t todo = __ballot(valid);
@@ -202,37 +179,40 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t *__restrict__ data, 
     }
 }
 
-// k_index_d: the fast variant, one wave per segment, two small LDS tables and no walking.
-//   head[h]  newest member so far.  One ds_wrxchg on it hands every lane the member inserted just before
-//            it, lanes of the same batch included, PROVIDED the LDS serialises same-address lanes of one
-//            instruction in ascending lane order.  gfx950 does (probed over 6.5*10^8 colliding exchanges,
-//            tools/probe/probe_exch.hip); the kernel still checks every returned value (a member handed out
-//            of order is not below the lane's own position) and raises bit 1 of *status, upon which the
+// k_index_r: the fast variant.  One wave per segment walks its positions DOWNWARD in batches of 64, with a
+// single LDS table and no walking:
+//   head[h]  the lowest member inserted so far, i.e. the nearest member above the position being inserted.
+//            One ds_wrxchg on it hands every lane its successor, lanes of the same batch included (lane l
+//            takes position u + 63 - l), PROVIDED the LDS serialises same-address lanes of one instruction in
+//            ascending lane order.  gfx950 does (probed over 6.5*10^8 colliding exchanges,
+//            tools/probe/probe_exch.hip); the kernel still checks every returned value (a successor handed
+//            out of order is not above the lane's own position) and raises bit 1 of *status, upon which the
 //            host redoes the call with k_index.
-//   entry[h] the newest position among (a) the members at least window + 1 behind the current group -- the
-//            same positions, inserted a second time with a lag of window + 64 * kIdxGroup -- and (b) the
-//            members that have no predecessor within the window (chain starts).  Both are kept with one
-//            atomic max.
-// For position q the chain runs unbroken from entry[h] up to q: if a chain start is the newer of the two it is
-// the farthest in-window member itself (or lies at most a group's span outside the window); otherwise no
-// chain start follows the lagging member, and the farthest in-window member is reached from it by following
-// forward links (one, or a few when the lag leaves members between it and the window's edge).  The kernel
-// stores that entry distance (possibly beyond the window, clipped at 65535) in far[]; k_far_fix follows the
-// links afterwards.
-// The warm-up before a segment is 2 * window + 64 * kIdxGroup positions: enough for every lagging entry
-// that can matter.
+// The successor gives next[] of the lane's own position: a contiguous store.  far[p] is read off the same
+// table when the walk has come down to p - window: head[h(p)] is then the lowest member at or above the
+// batch holding p - window, and at most a few links inside that batch (kept in LDS) lead from it to the lowest
+// member at or above p - window itself.  Positions less than a window above the first position of their slot
+// (the start of the data; the first byte of an isolated record) are answered in one sweep when the walk
+// reaches that first position.  Slots start on the grid of batch groups, so a group never straddles two.
+// A segment walks `window` positions above and below the ones it owns.
 #ifndef ZG_IDX_SEG_KB
-#define ZG_IDX_SEG_KB 192
+#define ZG_IDX_SEG_KB 128
 #endif
-constexpr uint32_t kIdxSegD = ZG_IDX_SEG_KB * 1024;  // positions owned by one k_index_d workgroup
+constexpr uint32_t kIdxSegD = ZG_IDX_SEG_KB * 1024;  // positions owned by one k_index_r workgroup
 #ifndef ZG_IDX_GROUP
 #define ZG_IDX_GROUP 4
 #endif
-constexpr uint32_t kIdxGroup = ZG_IDX_GROUP;        // batches of 64 positions handled together
-constexpr uint32_t kIdxLagPad = 64 * kIdxGroup;
+constexpr uint32_t kIdxGroup = ZG_IDX_GROUP;         // batches of 64 positions handled together
+constexpr uint32_t kIdxSpan = 64 * kIdxGroup;
+#ifndef ZG_IDX_DEPTH
+#define ZG_IDX_DEPTH 1
+#endif
+constexpr uint32_t kIdxDepth = ZG_IDX_DEPTH;         // groups whose keys are in flight
+constexpr uint32_t kIdxRBits = 13;
+constexpr uint32_t kIdxRBuckets = 1u << kIdxRBits;
 
 template <int K>
-__device__ __forceinline__ void index_d_segment(uint32_t *s_head, uint32_t *s_entry, uint32_t seg,
+__device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_link, uint32_t seg,
                                                 const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
                                                 uint64_t r1, uint64_t far_lo, uint32_t window,
                                                 uint16_t *__restrict__ far, uint16_t *__restrict__ next,
@@ -242,31 +222,29 @@ __device__ __forceinline__ void index_d_segment(uint32_t *s_head, uint32_t *s_en
     const uint64_t a = r0 + (uint64_t)seg * kIdxSegD;
     if (a >= r1) return;
     const uint64_t b = (a + kIdxSegD < r1) ? a + kIdxSegD : r1;
-    const uint32_t lag = window + kIdxLagPad;
-    const uint64_t warm = 2ull * window + kIdxLagPad;
-    const uint64_t a0 = a > warm ? a - warm : 0;
+    const uint32_t reach = (iso_bytes && iso_bytes < window) ? iso_bytes : window;  // longest link that can matter
+    const uint32_t rup = (reach + kIdxSpan - 1u) & ~(kIdxSpan - 1u);
+    const uint64_t a0 = (a - r0 > rup) ? a - rup : r0;        // lowest position walked; on the group grid from r0
+    const uint64_t top = (b + reach < r1) ? b + reach : r1;   // one past the highest position walked
 
-    for (uint32_t i = lane; i < kIdxBuckets; i += 64) {
-        s_head[i] = 0;
-        s_entry[i] = 0;
-    }
+    for (uint32_t i = lane; i < kIdxRBuckets; i += 64) s_head[i] = 0;
     __syncthreads();
 
     // everything below is relative to a0 and fits 32 bits
-    const uint32_t q_end = (uint32_t)(b - a0);
-    const uint32_t q_main = (uint32_t)(a - a0);
-    const uint32_t q_far = far_lo > a ? (uint32_t)(far_lo - a0) : q_main;   // first position whose far[] is stored
-    const uint32_t base_rel = base > a0 ? (uint32_t)(base - a0) : 0u;       // links below it have no slot
+    const uint32_t q_top = (uint32_t)(top - a0);
+    const uint32_t q_a = (uint32_t)(a - a0), q_b = (uint32_t)(b - a0);
+    const uint32_t q_far = far_lo > a ? (far_lo < b ? (uint32_t)(far_lo - a0) : q_b) : q_a;  // first far[] stored
     const uint64_t room = n_view - a0;
     const uint32_t n_rel = room < 0x7FFFFFFFull ? (uint32_t)room : 0x7FFFFFFFu;  // bytes from a0 to the view's end
-    const uint32_t last = n_rel - (K > 4 ? 8u : 4u);  // last offset a key load may start at (n_view >= 64)
+    // last offset a key load may start at; below zero when the view ends within a few bytes of a0 (n_view >= 64)
+    const int32_t last = (int32_t)n_rel - (K > 4 ? 8 : 4);
     const uint8_t *dseg = data + a0;
-    uint16_t *far_seg = far + ((int64_t)a0 - (int64_t)base);
-    uint16_t *next_seg = next + ((int64_t)a0 - (int64_t)base);
+    uint16_t *far_seg = far + (a0 - base);
+    uint16_t *next_seg = next + (a0 - base);
     bool violated = false;
 
     auto raw_at = [&](uint32_t q) -> RawKey<K> {  // branch-free: the offset is clamped into the view
-        const uint32_t qc = q < last ? q : last;
+        const int32_t qc = (int32_t)q < last ? (int32_t)q : last;
         RawKey<K> r;
         __builtin_memcpy(&r.a, dseg + qc, 4);
         r.b = 0;
@@ -274,191 +252,199 @@ __device__ __forceinline__ void index_d_segment(uint32_t *s_head, uint32_t *s_en
         return r;
     };
     auto hash_of = [&](RawKey<K> r, uint32_t q, bool exact) -> uint32_t {
-        if (exact) return key_hash<K>(r.a, r.b);  // the load was not clamped
-        const uint32_t sh = q > last ? ((q - last) & 7u) * 8u : 0u;
+        if (exact) return key_hash<K>(r.a, r.b) >> (32 - kIdxRBits);  // the load was not clamped
+        const uint32_t sh = (int32_t)q > last ? ((uint32_t)((int32_t)q - last) & 7u) * 8u : 0u;
         if (K > 4) {
             const uint64_t v = (((uint64_t)r.b << 32) | r.a) >> sh;
-            return key_hash<K>((uint32_t)v, (uint32_t)(v >> 32));
+            return key_hash<K>((uint32_t)v, (uint32_t)(v >> 32)) >> (32 - kIdxRBits);
         }
-        return key_hash<K>(r.a >> (sh & 31u), 0u);
+        return key_hash<K>(r.a >> (sh & 31u), 0u) >> (32 - kIdxRBits);
     };
 
-    // Positions are taken in groups of kIdxGroup batches.  The three steps of a group (insert the lagging
-    // positions and exchange the heads; mark chain starts; read entry[]) are issued for all its
-    // batches back to back, so that the wave waits for the LDS twice per group instead of twice per batch.
-    // Within a group this is safe: the lag keeps every lagging entry behind the window of every lane of the
-    // group, and a chain start cannot share its bucket with a lane less than a window before it.
-    RawKey<K> cur_m[kIdxGroup], cur_r[kIdxGroup], nxt_m[kIdxGroup], nxt_r[kIdxGroup];
-    // isolated slots: a link may not reach below the first byte of the position's slot.  rel = offset of this
-    // lane's first position of the group inside its slot (slots are >= 1024 bytes, a group spans 256).
-    uint32_t rel = iso_bytes ? (uint32_t)((a0 + lane - iso_first) % iso_bytes) : 0u;
-    auto group = [&](uint32_t qg, auto full_c) {
-        constexpr bool full = decltype(full_c)::value;  // every lane of the group is a position with K bytes
+    // One group = kIdxGroup batches, highest first.  Batch k of the group at qg inserts positions
+    // [u, u + 64), u = qg + 64 * (kIdxGroup - 1 - k), and right behind its exchange reads the table for the 64
+    // positions u + window + lane; none of these LDS operations waits for another, so the wave waits for the
+    // LDS once per group.  Keys of the next group are loaded meanwhile.
+    struct GroupKeys {
+        RawKey<K> m[kIdxGroup], r[kIdxGroup];  // keys of the positions inserted / looked up
+    };
+    auto ins_pos = [&](uint32_t qg, int k) { return qg + (kIdxSpan - 1u) - ((uint32_t)k * 64 + lane); };
+    auto look_pos = [&](uint32_t qg, int k) { return qg + (kIdxGroup - 1u - (uint32_t)k) * 64 + window + lane; };
+    // does any / every position looked up by the group at qg get its far[] from it?  (uniform)
+    auto look_none = [&](uint32_t qg, uint32_t slot_end) {
+        return qg + window >= q_b || qg + window >= slot_end || qg + window + kIdxSpan <= q_far;
+    };
+    auto look_all = [&](uint32_t qg, uint32_t slot_end) {
+        return qg + window >= q_far && qg + window + kIdxSpan <= q_b && qg + window + kIdxSpan <= slot_end;
+    };
+    auto slot_end_of = [&](uint32_t qg, uint32_t relg) { return iso_bytes ? qg + (iso_bytes - relg) : 0xFFFFFFFFu; };
+    // qg may be "below zero" (wrapped): its loads are clamped into the view and never used
+    auto load_keys = [&](GroupKeys &buf, uint32_t qg, bool with_look) {
 #pragma unroll
         for (int k = 0; k < (int)kIdxGroup; k++) {
-            const uint32_t q = qg + (kIdxGroup + (uint32_t)k) * 64 + lane;
-            nxt_m[k] = raw_at(q);
-            nxt_r[k] = raw_at(q >= lag ? q - lag : 0u);
+            const uint32_t qi = ins_pos(qg, k);
+            buf.m[k] = raw_at((int32_t)qi > 0 ? qi : 0u);
         }
-        uint32_t h[kIdxGroup], old1[kIdxGroup];
-        bool valid[kIdxGroup];
+        if (with_look) {
 #pragma unroll
-        for (int k = 0; k < (int)kIdxGroup; k++) {
-            const uint32_t q = qg + (uint32_t)k * 64 + lane;
-            valid[k] = full || (q < q_end && q + K <= n_rel);
-            h[k] = hash_of(cur_m[k], q, full);
-            const uint32_t hr = hash_of(cur_r[k], q - lag, true);  // a lagging position is never near the end
-            if (q >= lag) atomicMax(&s_entry[hr], q - lag + 1u);
-        }
-#pragma unroll
-        for (int k = 0; k < (int)kIdxGroup; k++) {
-            const uint32_t q = qg + (uint32_t)k * 64 + lane;
-            old1[k] = 0;
-            if (valid[k]) old1[k] = atomicExch(&s_head[h[k]], q + 1u);  // member inserted just before me (+1)
-        }
-        bool linked[kIdxGroup];
-#pragma unroll
-        for (int k = 0; k < (int)kIdxGroup; k++) {
-            const uint32_t q = qg + (uint32_t)k * 64 + lane;
-            violated |= old1[k] > q;
-            uint32_t reach = window;
-            if (iso_bytes) {
-                uint32_t r = rel + (uint32_t)k * 64;
-                r = r >= iso_bytes ? r - iso_bytes : r;
-                reach = r < window ? r : window;
+            for (int k = 0; k < (int)kIdxGroup; k++) {
+                const uint32_t ql = look_pos(qg, k);
+                buf.r[k] = raw_at((int32_t)ql > 0 ? ql : 0u);
             }
-            linked[k] = old1[k] != 0u && (q + 1u - old1[k]) <= reach;
-            if (valid[k] && !linked[k]) atomicMax(&s_entry[h[k]], q + 1u);
-        }
-        __builtin_amdgcn_wave_barrier();  // the LDS runs one wave's accesses in program order
-        uint32_t e1[kIdxGroup];
-#pragma unroll
-        for (int k = 0; k < (int)kIdxGroup; k++) e1[k] = s_entry[h[k]];
-#pragma unroll
-        for (int k = 0; k < (int)kIdxGroup; k++) {
-            const uint32_t q = qg + (uint32_t)k * 64 + lane;
-            uint32_t dist = 0;
-            if (valid[k]) {
-                dist = q + 1u - e1[k];  // entry[h] >= 1 here: the bucket's first member was a chain start
-                if (q >= q_main && linked[k] && old1[k] > base_rel) next_seg[old1[k] - 1u] = (uint16_t)(q + 1u - old1[k]);
-            }
-            if ((full || q < q_end) && q >= q_far) far_seg[q] = (uint16_t)(dist < 65535u ? dist : 65535u);
-        }
-#pragma unroll
-        for (int k = 0; k < (int)kIdxGroup; k++) {
-            cur_m[k] = nxt_m[k];
-            cur_r[k] = nxt_r[k];
-        }
-        if (iso_bytes) {
-            rel += 64 * kIdxGroup;
-            rel = rel >= iso_bytes ? rel - iso_bytes : rel;
         }
     };
+    // buf holds the keys of the group at qg and is refilled for the group kIdxDepth below (at qn, which looks
+    // positions up if look_n).  kNext / kLook: 0 = the group stores no next[] / answers no far[], 1 = every lane
+    // does, 2 = decided lane by lane.  kFull: every key of the group lies well inside the view.
+    auto group = [&](GroupKeys &buf, uint32_t qg, uint32_t slot_end, bool sweep, uint32_t qn, bool look_n, auto full_c,
+                     auto next_c, auto look_c) {
+        constexpr bool full = decltype(full_c)::value;
+        constexpr int kNext = decltype(next_c)::value, kLook = decltype(look_c)::value;
+        const GroupKeys cur = buf;
+        load_keys(buf, qn, look_n);
+        uint32_t old1[kIdxGroup], e1[kIdxGroup];
+        bool lv[kIdxGroup];
 #pragma unroll
-    for (int k = 0; k < (int)kIdxGroup; k++) {
-        const uint32_t q = (uint32_t)k * 64 + lane;
-        cur_m[k] = raw_at(q);
-        cur_r[k] = raw_at(0u);
+        for (int k = 0; k < (int)kIdxGroup; k++) {
+            const uint32_t qi = ins_pos(qg, k), ql = look_pos(qg, k);
+            const bool valid = full || (qi < q_top && qi + K <= n_rel);
+            const uint32_t h = hash_of(cur.m[k], qi, full);
+            old1[k] = 0;
+            if (valid) old1[k] = atomicExch(&s_head[h], qi + 1u);  // member inserted just before me (+1)
+            if (kLook) {
+                lv[k] = kLook == 1 || (ql >= q_far && ql < q_b && ql < slot_end && (full || ql + K <= n_rel));
+                e1[k] = s_head[hash_of(cur.r[k], ql, full)];
+            }
+        }
+        uint32_t e[kIdxGroup];
+        bool hop = false;
+#pragma unroll
+        for (int k = 0; k < (int)kIdxGroup; k++) {
+            const uint32_t qi = ins_pos(qg, k), ql = look_pos(qg, k);
+            violated |= old1[k] != 0u && old1[k] <= qi + 1u;
+            const uint32_t d = old1[k] ? old1[k] - 1u - qi : 0u;
+            if (kNext) {
+                // a link counts within the window and within the slot
+                const uint32_t nd = (d <= window && old1[k] - 1u < slot_end) ? d : 0u;
+                if (kNext == 1 || (qi >= q_a && qi < q_b)) next_seg[qi] = (uint16_t)nd;
+            }
+            if (kLook) {
+                s_link[qi - qg] = d;
+                e[k] = e1[k] ? e1[k] - 1u : ql;  // a valid position is a member itself: the bucket is not empty
+                hop |= lv[k] && e[k] < ql - window;
+            }
+        }
+        if (kLook) {
+            if (__any(hop)) {
+                // members of the batch below p - window: follow the batch's links upward
+                for (uint32_t guard = 0; guard < 64; ++guard) {
+                    bool more = false;
+#pragma unroll
+                    for (int k = 0; k < (int)kIdxGroup; k++) {
+                        const uint32_t ql = look_pos(qg, k);
+                        if (lv[k] && e[k] < ql - window) {
+                            const uint32_t l = s_link[e[k] - qg];
+                            e[k] = l ? e[k] + l : ql;
+                            more |= e[k] < ql - window;
+                        }
+                    }
+                    if (!__any(more)) break;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < (int)kIdxGroup; k++) {
+                const uint32_t ql = look_pos(qg, k);
+                if (kLook == 1 || (ql >= q_far && ql < q_b && ql < slot_end))
+                    far_seg[ql] = (uint16_t)(lv[k] ? ql - e[k] : 0u);
+            }
+        }
+        if (sweep) {
+            // qg is the first position of a slot: every member of the slot is in the table and nothing below it
+            uint32_t pe = qg + reach < q_b ? qg + reach : q_b;
+            pe = pe < slot_end ? pe : slot_end;
+            const uint32_t lo = qg > q_far ? qg : q_far;
+            for (uint32_t pb = qg + ((lo - qg) & ~63u); pb < pe; pb += kIdxSpan) {
+                RawKey<K> r[kIdxGroup];
+#pragma unroll
+                for (int j = 0; j < (int)kIdxGroup; j++) r[j] = raw_at(pb + (uint32_t)j * 64 + lane);
+#pragma unroll
+                for (int j = 0; j < (int)kIdxGroup; j++) {
+                    const uint32_t p = pb + (uint32_t)j * 64 + lane;
+                    const uint32_t m1 = s_head[hash_of(r[j], p, false)];
+                    if (p >= q_far && p < pe) far_seg[p] = (uint16_t)((p + K <= n_rel && m1) ? p + 1u - m1 : 0u);
+                }
+            }
+        }
+    };
+    const uint32_t n_groups = (q_top + kIdxSpan - 1u) / kIdxSpan;
+    // offset of a group's first position inside its slot (isolated slots only): relg for the group being
+    // handled, reln for the one whose keys are being loaded
+    auto rel_down = [&](uint32_t rel) { return rel >= kIdxSpan ? rel - kIdxSpan : rel + iso_bytes - kIdxSpan; };
+    uint32_t relg = iso_bytes ? (uint32_t)((a0 - iso_first + (uint64_t)(n_groups - 1u) * kIdxSpan) % iso_bytes) : 0u;
+    uint32_t reln = relg;
+    GroupKeys ring[kIdxDepth];
+#pragma unroll
+    for (uint32_t j = 0; j < kIdxDepth; j++) {
+        const uint32_t qn = (n_groups - 1u - j) * kIdxSpan;
+        load_keys(ring[j], qn, !look_none(qn, slot_end_of(qn, reln)));
+        if (iso_bytes) reln = rel_down(reln);
     }
-    constexpr uint32_t kSpan = 64 * kIdxGroup;
-    for (uint32_t qg = 0; qg < q_end; qg += kSpan) {
-        if (qg + kSpan <= q_end && qg + kSpan + 8u <= n_rel)
-            group(qg, std::true_type{});
-        else
-            group(qg, std::false_type{});
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    for (uint32_t g = n_groups; g > 0;) {
+#pragma unroll
+        for (uint32_t j = 0; j < kIdxDepth; j++) {  // unrolled, so that the ring stays in registers
+            if (g == 0) break;
+            --g;
+            const uint32_t qg = g * kIdxSpan, qn = qg - kIdxDepth * kIdxSpan;
+            const uint32_t slot_end = slot_end_of(qg, relg);
+            const bool sweep = iso_bytes ? relg == 0u : (g == 0u && a0 == r0);
+            const bool look_n = g >= kIdxDepth && !look_none(qn, slot_end_of(qn, reln));
+            const bool full = qg + kIdxSpan <= q_top && qg + kIdxSpan + window + 72u <= n_rel;
+            const bool n0 = qg >= q_b || qg + kIdxSpan <= q_a, n1 = qg >= q_a && qg + kIdxSpan <= q_b;
+            const bool l0 = look_none(qg, slot_end), l1 = look_all(qg, slot_end);
+            GroupKeys &buf = ring[j];
+            if (full && n1 && l1)
+                group(buf, qg, slot_end, sweep, qn, look_n, std::true_type{}, C1{}, C1{});
+            else if (full && n1 && l0)
+                group(buf, qg, slot_end, sweep, qn, look_n, std::true_type{}, C1{}, C0{});
+            else if (full && n0 && l1)
+                group(buf, qg, slot_end, sweep, qn, look_n, std::true_type{}, C0{}, C1{});
+            else if (full && n0 && l0)
+                group(buf, qg, slot_end, sweep, qn, look_n, std::true_type{}, C0{}, C0{});
+            else if (l0)
+                group(buf, qg, slot_end, sweep, qn, look_n, std::false_type{}, C2{}, C0{});
+            else
+                group(buf, qg, slot_end, sweep, qn, look_n, std::false_type{}, C2{}, C2{});
+            if (iso_bytes) {
+                relg = rel_down(relg);
+                reln = rel_down(reln);
+            }
+        }
     }
     if (__any(violated) && lane == 0) atomicOr(status, 2u);
 }
 
 // One workgroup (one wave) per segment and key length: blockIdx.y selects the five-byte or the three-byte
 // index, so that both are built by one launch and share the machine.
-__global__ __launch_bounds__(64) void k_index_d(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
+__global__ __launch_bounds__(64) void k_index_r(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
                                                  uint64_t r1, uint64_t far_lo, uint32_t window, int key_a, int key_b,
                                                  uint16_t *__restrict__ far_a, uint16_t *__restrict__ next_a,
                                                  uint16_t *__restrict__ far_b, uint16_t *__restrict__ next_b,
                                                  uint64_t base, uint32_t *status, uint64_t iso_first,
                                                  uint32_t iso_bytes) {
-    __shared__ uint32_t s_head[kIdxBuckets];   // position + 1, 0 = empty (both)
-    __shared__ uint32_t s_entry[kIdxBuckets];
+    __shared__ uint32_t s_head[kIdxRBuckets];  // position + 1, 0 = empty
+    __shared__ uint32_t s_link[kIdxSpan];      // distance to the successor, positions of the current group
     const int key = blockIdx.y == 0 ? key_a : key_b;
     uint16_t *far = blockIdx.y == 0 ? far_a : far_b;
     uint16_t *next = blockIdx.y == 0 ? next_a : next_b;
     if (key == 5)
-        index_d_segment<5>(s_head, s_entry, blockIdx.x, data, n_view, r0, r1, far_lo, window, far, next, base,
+        index_r_segment<5>(s_head, s_link, blockIdx.x, data, n_view, r0, r1, far_lo, window, far, next, base,
                            status, iso_first, iso_bytes);
     else
-        index_d_segment<3>(s_head, s_entry, blockIdx.x, data, n_view, r0, r1, far_lo, window, far, next, base,
+        index_r_segment<3>(s_head, s_link, blockIdx.x, data, n_view, r0, r1, far_lo, window, far, next, base,
                            status, iso_first, iso_bytes);
-}
-
-// k_far_fix: turns the entry distances k_index_d left in far[] into distances of the farthest in-window member.
-// Each thread takes kFixPer positions, 256 apart, so that their dependent link reads overlap.
-#ifndef ZG_FIX_PER
-#define ZG_FIX_PER 8
-#endif
-constexpr uint32_t kFixPer = ZG_FIX_PER;
-template <int K>
-__device__ __forceinline__ void far_fix_block(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t far_lo,
-                                              uint64_t r1, uint32_t window, uint16_t *__restrict__ far,
-                                              const uint16_t *__restrict__ next, uint64_t base) {
-    const uint64_t p0 = far_lo + (uint64_t)xcd_tile_index(blockIdx.x, gridDim.x) * (256 * kFixPer) + threadIdx.x;
-    const uint32_t d_max = 2u * window + kIdxLagPad - 1u;
-    uint32_t d[kFixPer];
-    bool live[kFixPer];
-#pragma unroll
-    for (uint32_t j = 0; j < kFixPer; j++) {
-        const uint64_t p = p0 + j * 256;
-        d[j] = p < r1 ? (uint32_t)far[p - base] : 0u;
-        live[j] = d[j] > window;
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < kFixPer; j++) {
-        if (live[j] && d[j] == 65535u && d_max > 65535u) {
-            // clipped: the entry is the nearest bucket member at distance 65535 or more (no member lies between
-            // it and that distance, or the index would have chosen that one)
-            const uint64_t p = p0 + j * 256;
-            const uint32_t hp = hash_at<K>(data, p, n_view);
-            uint32_t e = 0;
-            for (uint32_t t = 65535u; t <= d_max && (uint64_t)t <= p; t++)
-                if (hash_at<K>(data, p - t, n_view) == hp) {
-                    e = t;
-                    break;
-                }
-            d[j] = e;
-        }
-    }
-    for (int guard = 0; guard < 4096; ++guard) {
-        bool any = false;
-#pragma unroll
-        for (uint32_t j = 0; j < kFixPer; j++) {
-            const uint64_t p = p0 + j * 256;
-            if (d[j] > window) {
-                // a slot below the arrays or a missing link cannot occur on an unbroken chain while the arrays
-                // reach index_lookback() behind far_lo; treated as "no candidate"
-                const uint32_t nx = (p - d[j] >= base) ? (uint32_t)next[(p - d[j]) - base] : 0u;
-                d[j] = nx ? d[j] - nx : 0u;
-                any |= d[j] > window;
-            }
-        }
-        if (!any) break;
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < kFixPer; j++)
-        if (live[j]) far[(p0 + j * 256) - base] = (uint16_t)(d[j] <= window ? d[j] : 0u);
-}
-
-__global__ __launch_bounds__(256) void k_far_fix(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t far_lo,
-                                                  uint64_t r1, uint32_t window, int key_a, int key_b,
-                                                  uint16_t *__restrict__ far_a, const uint16_t *__restrict__ next_a,
-                                                  uint16_t *__restrict__ far_b, const uint16_t *__restrict__ next_b,
-                                                  uint64_t base) {
-    const int key = blockIdx.y == 0 ? key_a : key_b;
-    uint16_t *far = blockIdx.y == 0 ? far_a : far_b;
-    const uint16_t *next = blockIdx.y == 0 ? next_a : next_b;
-    if (key == 5)
-        far_fix_block<5>(data, n_view, far_lo, r1, window, far, next, base);
-    else
-        far_fix_block<3>(data, n_view, far_lo, r1, window, far, next, base);
 }
 
 // k_index_brute: the same two arrays for small windows (LZ77Compressor's default is 144), one thread per
@@ -503,6 +489,8 @@ static hipError_t launch_index_slow(const uint8_t *data, uint64_t n_view, uint64
                            r0, r1, far_lo, window, far, next, base, iso_first, iso_bytes);
     } else {
         const uint64_t nseg = (r1 - r0 + kIdxSegment - 1) / kIdxSegment;
+        const hipError_t e = hipMemsetAsync(next + (r0 - base), 0, (r1 - r0) * sizeof(uint16_t), s);  // links are scattered
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_index<K>, dim3((uint32_t)nseg), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, far,
                            next, base);
     }
@@ -531,18 +519,12 @@ hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint6
     }
     const uint32_t ny = key_b ? 2u : 1u;
     const uint64_t nseg = (r1 - r0 + kIdxSegD - 1) / kIdxSegD;
-    hipLaunchKernelGGL(k_index_d, dim3((uint32_t)nseg, ny), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, key_a,
+    hipLaunchKernelGGL(k_index_r, dim3((uint32_t)nseg, ny), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, key_a,
                        key_b, far_a, next_a, far_b, next_b, base, status, iso_first, iso_bytes);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (r1 > far_lo)
-        hipLaunchKernelGGL(k_far_fix, dim3((uint32_t)((r1 - far_lo + 256 * kFixPer - 1) / (256 * kFixPer)), ny),
-                           dim3(256), 0, s, data, n_view, far_lo, r1, window, key_a, key_b, far_a, next_a, far_b, next_b,
-                           base);
     return hipGetLastError();
 }
 
-uint64_t index_lookback(uint32_t window) { return 2ull * window + kIdxLagPad; }
+uint64_t index_lookback(uint32_t window) { return window; }
 
 // ---------------------------------------------------------------------------
 // k_match / k_match_lo: one workgroup per tile of kMatchTile positions.  The
