@@ -194,11 +194,8 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t *__restrict__ data, 
 // member at or above p - window itself.  Positions less than a window above the first position of their slot
 // (the start of the data; the first byte of an isolated record) are answered in one sweep when the walk
 // reaches that first position.  Slots start on the grid of batch groups, so a group never straddles two.
-// A segment walks `window` positions above and below the ones it owns.
-#ifndef ZG_IDX_SEG_KB
-#define ZG_IDX_SEG_KB 128
-#endif
-constexpr uint32_t kIdxSegD = ZG_IDX_SEG_KB * 1024;  // positions owned by one k_index_r workgroup
+// A segment walks `window` positions above and below the seg_len ones it owns; the host picks seg_len so that
+// the waves of a launch fill the machine a whole number of times.
 #ifndef ZG_IDX_GROUP
 #define ZG_IDX_GROUP 4
 #endif
@@ -208,20 +205,21 @@ constexpr uint32_t kIdxSpan = 64 * kIdxGroup;
 #define ZG_IDX_DEPTH 1
 #endif
 constexpr uint32_t kIdxDepth = ZG_IDX_DEPTH;         // groups whose keys are in flight
+constexpr uint32_t kIdxSegMin = 16u << 10, kIdxSegCap = 128u << 10;  // positions owned by one k_index_r wave
 constexpr uint32_t kIdxRBits = 13;
 constexpr uint32_t kIdxRBuckets = 1u << kIdxRBits;
 
 template <int K>
-__device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_link, uint32_t seg,
+__device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_link, uint32_t seg, uint32_t seg_len,
                                                 const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
                                                 uint64_t r1, uint64_t far_lo, uint32_t window,
                                                 uint16_t *__restrict__ far, uint16_t *__restrict__ next,
                                                 uint64_t base, uint32_t *status, uint64_t iso_first,
                                                 uint32_t iso_bytes) {
     const uint32_t lane = threadIdx.x;
-    const uint64_t a = r0 + (uint64_t)seg * kIdxSegD;
+    const uint64_t a = r0 + (uint64_t)seg * seg_len;
     if (a >= r1) return;
-    const uint64_t b = (a + kIdxSegD < r1) ? a + kIdxSegD : r1;
+    const uint64_t b = (a + seg_len < r1) ? a + seg_len : r1;
     const uint32_t reach = (iso_bytes && iso_bytes < window) ? iso_bytes : window;  // longest link that can matter
     const uint32_t rup = (reach + kIdxSpan - 1u) & ~(kIdxSpan - 1u);
     const uint64_t a0 = (a - r0 > rup) ? a - rup : r0;        // lowest position walked; on the group grid from r0
@@ -433,17 +431,17 @@ __global__ __launch_bounds__(64) void k_index_r(const uint8_t *__restrict__ data
                                                  uint16_t *__restrict__ far_a, uint16_t *__restrict__ next_a,
                                                  uint16_t *__restrict__ far_b, uint16_t *__restrict__ next_b,
                                                  uint64_t base, uint32_t *status, uint64_t iso_first,
-                                                 uint32_t iso_bytes) {
+                                                 uint32_t iso_bytes, uint32_t seg_len) {
     __shared__ uint32_t s_head[kIdxRBuckets];  // position + 1, 0 = empty
     __shared__ uint32_t s_link[kIdxSpan];      // distance to the successor, positions of the current group
     const int key = blockIdx.y == 0 ? key_a : key_b;
     uint16_t *far = blockIdx.y == 0 ? far_a : far_b;
     uint16_t *next = blockIdx.y == 0 ? next_a : next_b;
     if (key == 5)
-        index_r_segment<5>(s_head, s_link, blockIdx.x, data, n_view, r0, r1, far_lo, window, far, next, base,
+        index_r_segment<5>(s_head, s_link, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base,
                            status, iso_first, iso_bytes);
     else
-        index_r_segment<3>(s_head, s_link, blockIdx.x, data, n_view, r0, r1, far_lo, window, far, next, base,
+        index_r_segment<3>(s_head, s_link, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base,
                            status, iso_first, iso_bytes);
 }
 
@@ -518,9 +516,23 @@ hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint6
         return hipSuccess;
     }
     const uint32_t ny = key_b ? 2u : 1u;
-    const uint64_t nseg = (r1 - r0 + kIdxSegD - 1) / kIdxSegD;
+    // Segment length.  A wave walks its segment plus `reach` positions on either side, and the LDS table lets
+    // four waves share a CU.  Small inputs are cut so that one launch fills the machine once; large ones into
+    // segments of kIdxSegCap, short enough for waves on cheap and on costly data (long runs of one byte make
+    // every lane of a batch collide) to even out over several fillings.
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const uint64_t slots = 4ull * (uint64_t)cus, n_pos = r1 - r0;
+    const uint64_t reach = iso_bytes && iso_bytes < window ? iso_bytes : window;
+    const uint64_t cap = reach <= 4096 ? 4ull * kIdxSegCap : kIdxSegCap;
+    uint64_t seg_len = (n_pos * ny + slots - 1) / slots;
+    seg_len = (seg_len + kIdxSpan - 1) & ~(uint64_t)(kIdxSpan - 1);
+    seg_len = seg_len < kIdxSegMin ? kIdxSegMin : (seg_len > cap ? cap : seg_len);
+    const uint64_t nseg = (n_pos + seg_len - 1) / seg_len;
     hipLaunchKernelGGL(k_index_r, dim3((uint32_t)nseg, ny), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, key_a,
-                       key_b, far_a, next_a, far_b, next_b, base, status, iso_first, iso_bytes);
+                       key_b, far_a, next_a, far_b, next_b, base, status, iso_first, iso_bytes, (uint32_t)seg_len);
     return hipGetLastError();
 }
 
