@@ -122,10 +122,10 @@ int zg_decompress_batch_device(zg_ctx *ctx, const void *d_in, const uint64_t *d_
 /* ---- sharded compress: one rank of a multi-GPU job ----
  * A rank owns `n` input bytes (a whole number of chunks unless it is the last
  * rank) and sees `halo` (<= 32768) bytes of the input that precede them:
- * d_in points at the first halo byte.  zg_shard_begin runs everything up to
- * the block bit lengths and reports the rank's totals; after the ranks have
- * exchanged them, zg_shard_finish packs the rank's blocks at bit phase
- * (base_bit % 8) into d_out.  Byte 0 of d_out is byte base_bit/8 of the final
+ * d_in points at the first halo byte.  zg_shard_begin compresses the rank's
+ * chunks into blocks packed from bit 0 of a buffer the context keeps, and
+ * reports the rank's totals; after the ranks have exchanged them,
+ * zg_shard_finish moves the blocks to bit phase (base_bit % 8) in d_out.  Byte 0 of d_out is byte base_bit/8 of the final
  * stream; when the phase is non-zero it holds only this rank's bits and must
  * be OR-ed with the previous rank's last byte.  first_rank writes the 78 01
  * header in front of its blocks (base_bit must then be 16, the first bit after

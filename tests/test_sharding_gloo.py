@@ -50,9 +50,11 @@ class OracleEngine:
         return len(raw)
 
 
-def _worker(rank, world, port, total, chunk, q):
+def _worker(rank, world, port, total, chunk, q, piece=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if piece:
+        sharding.P2P_PIECE = piece  # payloads travel in several point-to-point operations
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         data = _corpus(total)
@@ -76,13 +78,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,total,chunk", [(2, 150_000, 16384), (2, 65536, 32768), (3, 100_000, 8192)])
-def test_sharded_assembly_equals_single_stream(world, total, chunk):
+@pytest.mark.parametrize("world,total,chunk,piece", [(2, 150_000, 16384, None), (2, 65536, 32768, None),
+                                                     (3, 100_000, 8192, None), (3, 100_000, 8192, 1000)])
+def test_sharded_assembly_equals_single_stream(world, total, chunk, piece):
     _lib.lib()  # adler32_combine comes from the product library (host function)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, chunk, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, chunk, q, piece)) for r in range(world)]
     for p in procs:
         p.start()
     stream = q.get(timeout=120)

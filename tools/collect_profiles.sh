@@ -6,16 +6,16 @@ OUT=$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="python3 bench.py --no-cpu-baseline --no-verify"
-for WL in text64m raw4g mixed1g records256m; do
+for WL in mixed8g text64m raw4g records256m; do
   echo "== stats $WL"
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -o r -- $B --steps 3 --warmup 1 --workload $WL > $OUT/stats_$WL.log 2>&1
 done
-for WL in text64m raw4g; do
+for WL in mixed8g text64m raw4g; do
   echo "== traffic $WL"
-  timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$WL -- $B --steps 1 --warmup 0 --workload $WL > $OUT/fetch_$WL.log 2>&1
-  timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$WL -- $B --steps 1 --warmup 0 --workload $WL > $OUT/write_$WL.log 2>&1
+  timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$WL -- $B --steps 1 --warmup 0 --workload $WL > $OUT/fetch_$WL.log 2>&1
+  timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$WL -- $B --steps 1 --warmup 0 --workload $WL > $OUT/write_$WL.log 2>&1
 done
 echo "== sq text64m"
-timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/sqa_text64m -- $B --steps 1 --warmup 0 > $OUT/sqa.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d $OUT/sqb_text64m -- $B --steps 1 --warmup 0 > $OUT/sqb.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/sqa_text64m -- $B --steps 1 --warmup 0 --workload text64m > $OUT/sqa.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d $OUT/sqb_text64m -- $B --steps 1 --warmup 0 --workload text64m > $OUT/sqb.log 2>&1
 echo done

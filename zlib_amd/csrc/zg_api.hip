@@ -63,13 +63,10 @@ struct zg_ctx {
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::string err;
-    DevBuf far, next, far3, next3, open_list, open_cnt, rec_len, rec_off, inf_off, inf_len, inf_status, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
+    DevBuf shard_buf, far, next, far3, next3, open_list, open_cnt, rec_len, rec_off, inf_off, inf_len, inf_status, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
         scalars, stage_in, stage_out, misc, flag, sub_exit, sub_exit2, merged, tile_cnt, adler_blk;
     // shard state kept between zg_shard_begin and zg_shard_finish
     bool shard_active = false;
-    ChunkGrid shard_grid{};
-    int shard_strategy = 0;
-    uint32_t shard_max_tiles = 0;
     uint64_t shard_total_bits = 0;
     // set once the exchange-based index kernel has reported an out-of-order exchange: use k_index from then on
     bool index_safe = false;
@@ -435,7 +432,7 @@ void zg_destroy(zg_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf *bufs[] = {&c->far, &c->next, &c->far3, &c->next3, &c->open_list, &c->open_cnt, &c->rec_len, &c->rec_off, &c->inf_off, &c->inf_len, &c->inf_status, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
+    DevBuf *bufs[] = {&c->shard_buf, &c->far, &c->next, &c->far3, &c->next3, &c->open_list, &c->open_cnt, &c->rec_len, &c->rec_off, &c->inf_off, &c->inf_len, &c->inf_status, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
                       &c->block_bits, &c->bit_off, &c->tile_bits, &c->adler_part, &c->scalars, &c->stage_in,
                       &c->stage_out, &c->misc, &c->flag, &c->sub_exit, &c->sub_exit2, &c->merged, &c->tile_cnt,
                       &c->adler_blk};
@@ -928,51 +925,55 @@ int zg_shard_begin(zg_ctx *ctx, const void *d_in, size_t halo, size_t n, int str
     g.end = halo + n;
     g.chunk_bytes = plan.chunk_bytes;
     g.n_chunks = n == 0 ? 1u : (uint32_t)((n + plan.chunk_bytes - 1) / plan.chunk_bytes);
-    if (g.n_chunks > 65535) return ZG_ERR_UNSUPPORTED;
     const uint32_t max_tiles = max_tiles_for(plan.chunk_bytes);
-    rc = ensure_chunk_meta(c, g.n_chunks, max_tiles);
-    if (rc) return rc;
-    rc = init_scalars(c, 0);
-    if (rc) return rc;
-    Scalars *sc = c->scalars.as<Scalars>();
+    const size_t bc = std::min<size_t>(plan.batch_chunks, g.n_chunks);
+    const size_t bound = (zg_compress_bound(n, strategy, opts) + 3) & ~(size_t)3;
     const MatchParams mp{kMaxWindow, 3, 258};
-    rc = run_front(c, g, 0, g.n_chunks, mp, strategy, last_rank ? (int64_t)g.n_chunks - 1 : -1, true);
-    if (rc) return rc;
-    // total bits of the rank's blocks: the block-offset scan with a zero carry
-    LAUNCH(K_TILEBITS, launch_tile_bits(g.n_chunks, max_tiles, c->tokens.as<uint32_t>(), g, 0, g.first,
-                                        c->ntok.as<uint32_t>(), c->tab.as<uint32_t>(), c->tile_bits.as<uint32_t>(),
-                                        c->stream));
-    LAUNCH(K_OFFSETS, launch_offsets(g.n_chunks, max_tiles, c->ntok.as<uint32_t>(), c->tile_bits.as<uint32_t>(),
-                                     c->block_bits.as<uint64_t>(), c->bit_off.as<uint64_t>(), &sc->carry, c->stream));
-    rc = run_adler(c, g.data + halo, n);
-    if (rc) return rc;
-    Scalars h;
-    HIPCHK(hipMemcpyAsync(&h, c->scalars.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if ((h.status & 2u) && !c->index_safe) {  // redo with the conservative index kernel
-        c->index_safe = true;
-        c->mu.unlock();
-        const int again = zg_shard_begin(c, d_in, halo, n, strategy, opts, last_rank, info);
-        c->mu.lock();
-        return again;
+    // The rank's blocks are packed from bit 0 of a buffer of its own, batch by batch as in a whole-stream call;
+    // zg_shard_finish moves them to the bit phase the stream gives them.
+    for (int attempt = 0;; attempt++) {
+        rc = ensure_chunk_meta(c, bc, max_tiles);
+        if (rc) return rc;
+        HIPCHK(c->shard_buf.ensure(bound + 8));
+        rc = init_scalars(c, 0);
+        if (rc) return rc;
+        LAUNCH(K_MISC, hipMemsetAsync(c->shard_buf.p, 0, bound + 8, c->stream));
+        for (uint32_t c0 = 0; c0 < g.n_chunks; c0 += (uint32_t)bc) {
+            const uint32_t c1 = (uint32_t)std::min<uint64_t>(g.n_chunks, (uint64_t)c0 + bc);
+            const int64_t final_chunk = (last_rank && c1 == g.n_chunks) ? (int64_t)(c1 - c0 - 1) : -1;
+            rc = run_front(c, g, c0, c1, mp, strategy, final_chunk, true);
+            if (rc) return rc;
+            rc = run_back(c, g, c0, c1, max_tiles, c->shard_buf.as<uint32_t>(), (uint64_t)bound * 8);
+            if (rc) return rc;
+        }
+        rc = run_adler(c, g.data + halo, n);
+        if (rc) return rc;
+        Scalars h;
+        HIPCHK(hipMemcpyAsync(&h, c->scalars.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if ((h.status & 2u) && !c->index_safe && attempt == 0) {  // redo with the conservative index kernel
+            c->index_safe = true;
+            continue;
+        }
+        if (h.status & 1u) return ZG_ERR_CAPACITY;
+        info->total_bits = h.carry;
+        info->adler = (h.adler[1] << 16) | h.adler[0];
+        info->n_chunks = g.n_chunks;
+        c->shard_total_bits = h.carry;
+        c->shard_active = true;
+        return ZG_OK;
     }
-    info->total_bits = h.carry;
-    info->adler = (h.adler[1] << 16) | h.adler[0];
-    info->n_chunks = g.n_chunks;
-    c->shard_grid = g;
-    c->shard_strategy = strategy;
-    c->shard_max_tiles = max_tiles;
-    c->shard_total_bits = h.carry;
-    c->shard_active = true;
-    return ZG_OK;
 }
 
-// The block offsets computed in zg_shard_begin are relative to bit 0; finish shifts them by the rank's
-// start bit inside d_out.
 namespace {
-__global__ void k_shift_offsets(uint64_t *bit_off, uint32_t n, uint64_t delta) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) bit_off[i] += delta;
+// out = in shifted up by s bits (0 <= s <= 16), as 32-bit little-endian words
+__global__ __launch_bounds__(256) void k_shift_bits(const uint32_t *__restrict__ in, uint64_t n_in,
+                                                     uint32_t *__restrict__ out, uint64_t n_out, uint32_t s) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_out) return;
+    const uint32_t hi = j < n_in ? in[j] : 0u;
+    const uint32_t lo = (j >= 1 && j - 1 < n_in) ? in[j - 1] : 0u;
+    out[j] = s ? (hi << s) | (lo >> (32 - s)) : hi;
 }
 }  // namespace
 
@@ -986,24 +987,19 @@ int zg_shard_finish(zg_ctx *ctx, uint64_t base_bit, int first_rank, int last_ran
     if (!c->shard_active) return ZG_ERR_ARG;
     if (first_rank && base_bit != 16) return ZG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    const ChunkGrid &g = c->shard_grid;
     Scalars *sc = c->scalars.as<Scalars>();
     const uint64_t local0 = first_rank ? 16 : (base_bit & 7);  // bit offset of the first block inside d_out
     const uint64_t end_bit = local0 + c->shard_total_bits;
     const uint64_t need = ((end_bit + 7) >> 3) + (last_rank ? 4 : 0);
-    if (out_cap < ((need + 3) & ~(uint64_t)3)) return ZG_ERR_CAPACITY;
-    LAUNCH(K_MISC, hipMemsetAsync(d_out, 0, (need + 3) & ~(uint64_t)3, c->stream));
+    const uint64_t padded = (need + 3) & ~(uint64_t)3;
+    if (out_cap < padded) return ZG_ERR_CAPACITY;
     {
-        ProfScope ps(c, K_OFFSETS);
-        hipLaunchKernelGGL(k_shift_offsets, dim3((g.n_chunks + 255) / 256), dim3(256), 0, c->stream,
-                           c->bit_off.as<uint64_t>(), g.n_chunks, local0);
+        ProfScope ps(c, K_ENCODE);
+        const uint64_t n_in = (c->shard_total_bits + 31) / 32, n_out = padded / 4;
+        hipLaunchKernelGGL(k_shift_bits, dim3((uint32_t)((n_out + 255) / 256)), dim3(256), 0, c->stream,
+                           c->shard_buf.as<uint32_t>(), n_in, static_cast<uint32_t *>(d_out), n_out, (uint32_t)local0);
         HIPCHK(hipGetLastError());
     }
-    LAUNCH(K_ENCODE, launch_encode(g.n_chunks, c->shard_max_tiles, c->tokens.as<uint32_t>(), g, 0, g.first,
-                                   c->ntok.as<uint32_t>(), c->tab.as<uint32_t>(), c->hdr.as<uint32_t>(),
-                                   c->hdr_bits.as<uint32_t>(), c->tile_bits.as<uint32_t>(), c->bit_off.as<uint64_t>(),
-                                   static_cast<uint32_t *>(d_out), (uint64_t)(((need + 3) & ~(uint64_t)3)) * 8,
-                                   &sc->status, c->stream));
     HIPCHK(hipMemcpyAsync(&sc->carry, &end_bit, sizeof end_bit, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     LAUNCH(K_MISC, launch_trailer(static_cast<uint8_t *>(d_out), &sc->carry, sc->adler, adler, 1, first_rank ? 1 : 0,

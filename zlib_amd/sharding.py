@@ -22,6 +22,7 @@ from typing import List, Tuple
 from . import api
 
 ADLER_INIT = 1
+P2P_PIECE = 1 << 30  # bytes per point-to-point operation (some backends count a message in 32 bits)
 ZLIB_HEADER_BITS = 16
 
 
@@ -89,30 +90,44 @@ def compress_sharded(engine, dist, torch, rank: int, world: int, device, final=N
     out = engine.out
     # payload exchange: every rank's bytes go to rank 0 in one grouped batch of point-to-point operations (all
     # peers in flight together, one hop each); the first byte of a rank travels apart because rank 0 may have
-    # to OR it into a byte the previous rank also wrote
+    # to OR it into a byte the previous rank also wrote.  RCCL moves device memory directly; other backends
+    # (gloo, used to rehearse the path) only do point-to-point on host tensors, so the bytes are staged.
+    staged = out.is_cuda and dist.get_backend() != "nccl"
     if first:
         final[:nb].copy_(out[:nb])
         edges = scratch.setdefault("edges", torch.zeros(max(1, world), dtype=torch.uint8, device=device))
-        ops, spans = [], []
+        ops, spans, landed = [], [], []
+
+        def recv_into(view, r):
+            if staged:
+                host = torch.empty(view.numel(), dtype=torch.uint8)
+                landed.append((view, host))
+                view = host
+            ops.append(dist.P2POp(dist.irecv, view, r))
+
         for r in range(1, world):
             off = bases[r] // 8
             stop = total_bytes if r == world - 1 else (bases[r + 1] + 7) // 8
             spans.append((r, off))
-            ops.append(dist.P2POp(dist.irecv, edges[r:r + 1], r))
-            if stop - off > 1:
-                ops.append(dist.P2POp(dist.irecv, final[off + 1:stop], r))
+            recv_into(edges.narrow(0, r, 1), r)
+            for lo in range(off + 1, stop, P2P_PIECE):
+                recv_into(final[lo:min(stop, lo + P2P_PIECE)], r)
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        for view, host in landed:
+            view.copy_(host)
         for r, off in spans:  # in rank order: a rank's first byte lands before the next rank's tail is merged
+            # one-element views, not integer indexing: the offsets pass 2^31 on multi-GiB streams
             if bases[r] % 8:
-                final[off] |= edges[r]  # the byte two neighbouring ranks share
+                final.narrow(0, off, 1).bitwise_or_(edges.narrow(0, r, 1))  # the byte two neighbouring ranks share
             else:
-                final[off] = edges[r]
+                final.narrow(0, off, 1).copy_(edges.narrow(0, r, 1))
     else:
-        ops = [dist.P2POp(dist.isend, out[0:1], 0)]
-        if nb > 1:
-            ops.append(dist.P2POp(dist.isend, out[1:nb], 0))
+        src = out[:nb].cpu() if staged else out
+        ops = [dist.P2POp(dist.isend, src[0:1], 0)]
+        for lo in range(1, nb, P2P_PIECE):
+            ops.append(dist.P2POp(dist.isend, src[lo:min(nb, lo + P2P_PIECE)], 0))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return total_bytes
