@@ -38,6 +38,10 @@ WORKLOADS = {
     "text64m": ("text", 64 << 20, 1 << 20, 0x5EED0001, "Dynamic"),   # 64 MiB of text on a single GPU
     "mixed1g": ("mixed", 1 << 30, 1 << 20, 0x5EED0004, "Dynamic"),   # what one of 8 GPUs gets of mixed8g
     "text1g": ("text", 1 << 30, 1 << 20, 0x5EED0001, "Dynamic"),
+    # the three kinds of MiB segment the mixed corpus is made of (2 : 1 : 1), each alone
+    "text256m": ("text", 256 << 20, 1 << 20, 0x5EED0001, "Dynamic"),
+    "random256m": ("random", 256 << 20, 1 << 20, 0x5EED0003, "Dynamic"),
+    "binary256m": ("binary", 256 << 20, 1 << 20, 0x5EED0004, "Dynamic"),
     "raw4g": ("random", 4 << 30, 1 << 20, 0x5EED0003, "Raw"),        # configs[2]: stored blocks + Adler-32
     "raw1g": ("random", 1 << 30, 1 << 20, 0x5EED0003, "Raw"),
     # configs[4]: records of 4 KiB, each compressed as a zlib stream of its own ("chunk" = record size)

@@ -203,6 +203,30 @@ def test_long_runs_and_periodic_data(za, z):
             assert sysz.decompress(got) == data
 
 
+@pytest.mark.gpu
+def test_motif_soup_long_chains_with_periodic_neighbourhoods(za, z):
+    """Few symbols, short motifs repeated a random number of times: five-byte chains thousands of members long,
+    best lengths that grow step by step along them, and search-ending candidates a few bytes before the
+    position -- the cases in which the level-1 walk changes to a more selective chain."""
+    import random
+    comp = za.zlib_compressor()
+    for seed in range(6):
+        rng = random.Random(1000 + seed)
+        motifs = [bytes(rng.choice(b"abc") for _ in range(rng.randint(1, 9))) for _ in range(12)]
+        parts, n = [], 0
+        while n < 90_000:
+            m = rng.choice(motifs) * rng.randint(1, 6)
+            if rng.random() < 0.05:
+                m += bytes([rng.randrange(256)])
+            parts.append(m)
+            n += len(m)
+        data = b"".join(parts)
+        _same(comp.compress_packed(data), z.lz77_zlib(data, fast=True), f"motif soup {seed}")
+    # a frequent five bytes followed by a counter: the chain of the sixth byte is short
+    rec = b"".join(b"\x3f\x00\x00\x00\x00" + i.to_bytes(4, "little") + bytes([(i * 7) & 0xFF, 0, 0]) for i in range(9000))
+    _same(comp.compress_packed(rec), z.lz77_zlib(rec, fast=True), "counter records")
+
+
 def test_batching_does_not_change_the_stream(za):
     data = za.corpus("text", 700_000)
     a = za.compress(data, za.Strategy.Dynamic, chunk_bytes=65536)

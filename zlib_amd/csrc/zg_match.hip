@@ -664,6 +664,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     const uint32_t min_len = mp.min_len, max_len = mp.max_len;
     const uint32_t tn = (uint32_t)(t1 - t0);
     const uint32_t pbase = (uint32_t)(t0 - w0);  // LDS offset of tile position 0
+    const uint32_t lo_off = (uint32_t)(wlo - w0); // LDS offset of the lowest candidate there is
     const uint16_t *far_t = far + (t0 - base);
     const uint16_t *far_lo_t = emit_term ? far_lo + (t0 - base) : far_t;
     uint2 *open_t = open_list + (uint64_t)bid * G::tile;
@@ -679,6 +680,17 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
 #define ZG_FETCH_BATCH 2
 #endif
     constexpr uint32_t kEvalBatch = ZG_EVAL_BATCH, kFetchBatch = ZG_FETCH_BATCH;
+#ifndef ZG_SWITCH_TRIPS
+#define ZG_SWITCH_TRIPS 4
+#endif
+#ifndef ZG_SWITCH_REMAIN
+#define ZG_SWITCH_REMAIN 256
+#endif
+#ifndef ZG_SWITCH_BATCH
+#define ZG_SWITCH_BATCH 4
+#endif
+    // a walk may change chains after kSwitchTrips trips (0: never), once kSwitchBatch lanes want to
+    constexpr uint32_t kSwitchTrips = ZG_SWITCH_TRIPS, kSwitchBatch = ZG_SWITCH_BATCH, kSwitchRemain = ZG_SWITCH_REMAIN;
     // what a lane is doing: walking (hd), waiting to have a candidate measured (ev), waiting to retire its
     // position and claim another (ft), or none of them (no positions left).  Kept as predicates, so that the
     // bookkeeping of a head step is scalar mask arithmetic.
@@ -687,6 +699,18 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     int32_t so_near = 0, so_end = 0;  // candidates at or above: within max_len of the position / past the loop guard
     const uint32_t mask0 = rec_min >= 4 ? 0xFFFFFFFFu : 0x00FFFFFFu;  // first-bytes probe
     uint32_t toff = 0, pt = 0, tmask = mask0;  // far-candidate probe: offset, expected bytes, byte mask
+    // Chain switching.  Once a candidate has matched `best` >= 6 bytes, every candidate that can beat it agrees
+    // with the position in bytes best-5 .. best-1 as well, so it is found on the chain of position pos + o,
+    // o = best - 5, o positions above the candidate itself -- often a far shorter chain (a frequent five bytes
+    // followed by a rare sixth).  The best candidate, moved up by o, is a member of that chain, so the walk can
+    // continue from there.  The cursor `so` is therefore a CHAIN position: the candidate is so - o, and
+    // so_near, so_end, toff and noff (= -o) are kept shifted by o so that a head step costs the same.
+    // Candidates the new chain skips match fewer than `best` bytes; they matter only if one of them would end
+    // the search (distance d <= its length + 1, hence d <= best): those few distances are tested directly
+    // when the walk changes chains.  Only walks that have run long change chains.
+    uint32_t noff = 0;    // minus the chain offset o
+    uint32_t st = 0;      // o | largest distance tested for a search-ending candidate << 8 | trips since the claim << 17
+    bool need_sw = false; // best has grown since the chain was chosen
     uint32_t termd = 0;                        // distance of the candidate that ended the search, if one did
     bool has_pos = false;  // a position is loaded and its result is not yet written
     uint32_t nxt_idx = atomicAdd(&s_counter, 1u);
@@ -698,7 +722,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
 #pragma unroll
         for (int step = 0; step < kHeadSteps; step++) {
             const bool nearby = (int32_t)so >= so_near;  // may end the search: its first bytes decide
-            const uint32_t off = nearby ? 0u : toff;
+            const uint32_t off = nearby ? noff : toff;
             const uint32_t want = nearby ? p0 : pt;
             const uint32_t msk = nearby ? mask0 : tmask;
             const uint32_t w = lds_ld4(s_data, so + off);
@@ -719,6 +743,8 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
         if (n_eval >= kEvalBatch || (n_eval != 0 && n_head == 0)) {
             if (ev) {
                 uint32_t m;
+                const uint32_t sc = so;  // chain position of the candidate
+                so += noff;              // the candidate itself
                 const uint32_t x0 = lds_ld4(s_data, so) ^ p0;
                 if (x0) {
                     m = (uint32_t)__builtin_ctz(x0) >> 3;
@@ -748,20 +774,63 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                     } else if (m > best) {
                         best = m;
                         bestd = d;
-                        toff = m - 3;
-                        pt = lds_ld4(s_data, po + toff);
+                        pt = lds_ld4(s_data, po + m - 3);
+                        toff = m - 3 + noff;
                         tmask = 0xFFFFFFFFu;
                         finish = m == cap;  // cannot be exceeded
+                        need_sw = kSwitchTrips != 0 && m >= 6;
+                        st &= 0x1FFFFu;  // trips are counted from the best candidate on
                     }
                 }
-                const uint32_t nx = s_next[so];
-                so += nx;
+                const uint32_t nx = s_next[sc];
+                so = sc + nx;
                 ev = false;
                 ft = finish || nx == 0;
                 hd = !ft;
             }
             n_head = (uint32_t)__popcll(__ballot(hd));
             n_eval = 0;
+        }
+        // ---- long walks: move to the chain that the best length so far selects ----
+        st += 1u << 17;
+        if (kSwitchTrips != 0) {
+            // worth it when the chain walked now is dense: at the rate of members per byte seen since the best
+            // candidate, more than kSwitchRemain steps are left before the position
+            const uint32_t trips = st >> 17, dcur = po - so - noff, cov = bestd - dcur;
+            const bool sw = hd & need_sw & (trips >= kSwitchTrips) &
+                            (trips * (uint32_t)kHeadSteps * (dcur >> 4) >= kSwitchRemain * (cov >> 4));
+            const uint32_t n_sw = (uint32_t)__popcll(__ballot(sw));
+            if (n_sw >= kSwitchBatch || (n_sw != 0 && n_sw * 4 >= n_head)) {
+                if (sw) {
+                    const uint32_t o_old = st & 0xFFu, tchk = (st >> 8) & 0x1FFu;
+                    const uint32_t room = pbase + tn - po;  // links are staged up to the end of the tile
+                    uint32_t o_new = best - 5u;
+                    o_new = o_new < room ? o_new : room;
+                    o_new = o_new < 255u ? o_new : 255u;
+                    if (o_new > o_old) {
+                        int32_t end_u = so_end - (int32_t)o_old;
+                        // a skipped candidate at distance d ends the search iff it matches max(rec_min, d - 1) bytes
+                        const uint32_t d_lo = tchk > min_len ? tchk : min_len;
+                        uint32_t d_hi = best < po - lo_off ? best : po - lo_off;
+                        for (uint32_t d = d_hi; d > d_lo; --d) {
+                            if (lds_ld4(s_data, po - d) != p0) continue;  // rec_min >= 5: four equal bytes at least
+                            const uint32_t need = d - 1u > rec_min ? d - 1u : rec_min;
+                            if (need <= cap && (int32_t)(po - d) < end_u && lds_lcp(s_data, po - d, po, need) >= need) {
+                                end_u = (int32_t)(po - d);
+                                break;
+                            }
+                        }
+                        so = po - bestd + o_new;
+                        so_near = (int32_t)po - (int32_t)max_len + (int32_t)o_new;
+                        so_end = end_u + (int32_t)o_new;
+                        noff = 0u - o_new;
+                        toff = best - 3u - o_new;
+                        st = (best << 8) | o_new;  // trips start again
+                    }
+                    need_sw = false;
+                }
+                n_head = (uint32_t)__popcll(__ballot(hd));
+            }
         }
         // ---- retire finished positions and claim new ones ----
         const uint32_t n_fetch = (uint32_t)__popcll(__ballot(ft));
@@ -802,9 +871,12 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                         toff = 0;
                         pt = p0;
                         tmask = mask0;
+                        noff = 0;
+                        st = 0;
                         hd = true;
                         ft = false;
                     }
+                    need_sw = false;
                     nxt_idx = atomicAdd(&s_counter, 1u);
                     const uint32_t ni = nxt_idx < tn ? nxt_idx : 0u;  // unconditional loads: tn >= 1 here
                     nxt_far = far_t[ni];
