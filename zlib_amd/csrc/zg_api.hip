@@ -63,7 +63,7 @@ struct zg_ctx {
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::string err;
-    DevBuf shard_buf, far, next, far3, next3, open_list, open_cnt, rec_len, rec_off, inf_off, inf_len, inf_status, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
+    DevBuf shard_buf, far, next, far4, next4, far3, next3, open_list, open_far, open_cnt, rec_len, rec_off, inf_off, inf_len, inf_status, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
         scalars, stage_in, stage_out, misc, flag, sub_exit, sub_exit2, merged, tile_cnt, adler_blk;
     // shard state kept between zg_shard_begin and zg_shard_finish
     bool shard_active = false;
@@ -220,6 +220,8 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
     HIPCHK(c->far.ensure(span * 2 + 64));
     HIPCHK(c->next.ensure(span * 2 + 64));
     if (two_level) {
+        HIPCHK(c->far4.ensure(span * 2 + 64));
+        HIPCHK(c->next4.ensure(span * 2 + 64));
         HIPCHK(c->far3.ensure(span * 2 + 64));
         HIPCHK(c->next3.ensure(span * 2 + 64));
     }
@@ -227,24 +229,29 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
     HIPCHK(c->tokens.ensure((be - bs) * 4 + 64));
     if (span) {
         uint32_t *status = &c->scalars.as<Scalars>()->status;
+        IndexSet set;
+        set.add(5, c->far.as<uint16_t>(), c->next.as<uint16_t>());
         if (two_level) {
             const uint64_t ntiles = (uint64_t)(c1 - c0) * match_tiles_per_chunk(g);
-            HIPCHK(c->open_list.ensure(ntiles * match_tile_positions(g) * sizeof(uint2)));
+            HIPCHK(c->open_list.ensure(ntiles * match_tile_positions(g) * sizeof(uint32_t)));
+            HIPCHK(c->open_far.ensure(ntiles * match_tile_positions(g) * sizeof(uint32_t)));
             HIPCHK(c->open_cnt.ensure(ntiles * sizeof(uint32_t)));
+            set.add(4, c->far4.as<uint16_t>(), c->next4.as<uint16_t>());
+            set.add(3, c->far3.as<uint16_t>(), c->next3.as<uint16_t>());
         }
-        LAUNCH(K_INDEX, launch_index(g.data, g.end, ix0, be, bs, mp.window, 5, c->far.as<uint16_t>(),
-                                     c->next.as<uint16_t>(), two_level ? 3 : 0, c->far3.as<uint16_t>(),
-                                     c->next3.as<uint16_t>(), ib0, status, c->index_safe, iso_first, iso_bytes,
-                                     c->stream));
+        LAUNCH(K_INDEX, launch_index(g.data, g.end, ix0, be, bs, mp.window, set, ib0, status, c->index_safe, iso_first,
+                                     iso_bytes, c->stream));
         if (two_level) {
             LAUNCH(K_MATCH, launch_match(g, c0, c1, mp, rec_min, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
-                                         c->match.as<uint32_t>(), c->far3.as<uint16_t>(), c->open_list.as<uint2>(),
+                                         c->match.as<uint32_t>(), c->open_list.as<uint32_t>(),
                                          c->open_cnt.as<uint32_t>(), c->stream));
-            LAUNCH(K_MATCH_LO, launch_match_lo(g, c0, c1, mp, c->next3.as<uint16_t>(), ib0, c->match.as<uint32_t>(),
-                                               c->open_list.as<uint2>(), c->open_cnt.as<uint32_t>(), c->stream));
+            LAUNCH(K_MATCH_LO, launch_match_lo(g, c0, c1, mp, c->far4.as<uint16_t>(), c->next4.as<uint16_t>(),
+                                               c->far3.as<uint16_t>(), c->next3.as<uint16_t>(), ib0,
+                                               c->match.as<uint32_t>(), c->open_list.as<uint32_t>(),
+                                               c->open_far.as<uint32_t>(), c->open_cnt.as<uint32_t>(), c->stream));
         } else {
             LAUNCH(K_MATCH, launch_match(g, c0, c1, mp, rec_min, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
-                                         c->match.as<uint32_t>(), nullptr, nullptr, nullptr, c->stream));
+                                         c->match.as<uint32_t>(), nullptr, nullptr, c->stream));
         }
     }
     {
@@ -432,7 +439,7 @@ void zg_destroy(zg_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf *bufs[] = {&c->shard_buf, &c->far, &c->next, &c->far3, &c->next3, &c->open_list, &c->open_cnt, &c->rec_len, &c->rec_off, &c->inf_off, &c->inf_len, &c->inf_status, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
+    DevBuf *bufs[] = {&c->shard_buf, &c->far, &c->next, &c->far4, &c->next4, &c->far3, &c->next3, &c->open_list, &c->open_far, &c->open_cnt, &c->rec_len, &c->rec_off, &c->inf_off, &c->inf_len, &c->inf_status, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
                       &c->block_bits, &c->bit_off, &c->tile_bits, &c->adler_part, &c->scalars, &c->stage_in,
                       &c->stage_out, &c->misc, &c->flag, &c->sub_exit, &c->sub_exit2, &c->merged, &c->tile_cnt,
                       &c->adler_blk};

@@ -87,22 +87,33 @@ __device__ __forceinline__ uint64_t chunk_end(uint64_t cs, uint64_t chunk_bytes,
 // view position `base` <= r0.  Every next[] of [r0, r1) and far[] of [far_lo, r1) is written.
 // iso_bytes != 0: positions belong to slots of iso_bytes (a multiple of 1024) starting at iso_first, chains
 // never leave a slot, and r0 is the first byte of a slot.
-// Builds the index for key length key_a and, unless key_b is 0, a second one for key_b in the same launches.
+// One launch builds the index for every key length of the set (3, 4 or 5 bytes).
+struct IndexSet {
+    uint32_t n = 0;
+    int key[3] = {0, 0, 0};
+    uint16_t *far[3] = {nullptr, nullptr, nullptr};
+    uint16_t *next[3] = {nullptr, nullptr, nullptr};
+    void add(int k, uint16_t *f, uint16_t *nx) {
+        key[n] = k;
+        far[n] = f;
+        next[n] = nx;
+        n++;
+    }
+};
 hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
-                        uint32_t window, int key_a, uint16_t *far_a, uint16_t *next_a, int key_b, uint16_t *far_b,
-                        uint16_t *next_b, uint64_t base, uint32_t *status, bool safe, uint64_t iso_first,
-                        uint32_t iso_bytes, hipStream_t s);
+                        uint32_t window, const IndexSet &set, uint64_t base, uint32_t *status, bool safe,
+                        uint64_t iso_first, uint32_t iso_bytes, hipStream_t s);
 uint64_t index_lookback(uint32_t window);
-// level 1: lengths >= rec_min along the five-byte chains.  With far_lo (the far[] of the three-byte index)
-// it also lists, per tile, the positions it leaves without a length and that have three-byte candidates:
-// open_list[tile * match_tile_positions(g) + i] = (tile position | distance of a search-ending candidate << 16, far_lo),
-// open_cnt[tile] entries.
+// level 1: lengths >= rec_min along the five-byte chains.  With open_list it also lists, per tile, the positions
+// it leaves without a length (tile position | distance of the candidate that ended the search << 16; a tile's
+// list starts at tile index * match_tile_positions(g), its length goes to open_cnt[tile index]).
 hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, uint32_t rec_min,
                         const uint16_t *far, const uint16_t *next, uint64_t base, uint32_t *match,
-                        const uint16_t *far_lo, uint2 *open_list, uint32_t *open_cnt, hipStream_t s);
-// level 2: lengths 3 and 4 along the three-byte chains, for the listed positions
-hipError_t launch_match_lo(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *next,
-                           uint64_t base, uint32_t *match, const uint2 *open_list, const uint32_t *open_cnt,
+                        uint32_t *open_list, uint32_t *open_cnt, hipStream_t s);
+// level 2: lengths 3 and 4 for the listed positions, from the four-byte and the three-byte index
+hipError_t launch_match_lo(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *far4,
+                           const uint16_t *next4, const uint16_t *far3, const uint16_t *next3, uint64_t base,
+                           uint32_t *match, uint32_t *open_list, uint32_t *open_far, const uint32_t *open_cnt,
                            hipStream_t s);
 hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint32_t *match, uint64_t base,
                         uint8_t *flag, uint64_t flag_bytes, uint32_t *sub_exit, uint32_t *sub_exit2, uint8_t *merged,

@@ -1,6 +1,5 @@
-// LZ77 match finding for gfx950: forward-chain K-gram indexes (K = 5 and K = 3)
-// and an exhaustive, position-parallel longest-match search over LDS-staged
-// windows, in two levels.  Together they reproduce, for EVERY position of a
+// LZ77 match finding for gfx950: forward-chain K-gram indexes (K = 5, 4 and 3)
+// and an exhaustive, position-parallel longest-match search, in two levels.  Together they reproduce, for EVERY position of a
 // chunk, the result of the candidate loop of LZ77Compressor::compress
 // (reference src/lz77.rs:156-190):
 //
@@ -22,17 +21,14 @@
 // Level 2 (k_match_lo, only when min_len <= 4) takes the positions level 1 left
 // open.  All their candidates below T match fewer than five bytes, so the
 // answer is the farthest candidate with four common bytes, else the farthest
-// with three: a walk along the THREE-byte chain that stops at the first
-// four-byte agreement.
+// with three: the first true member of the FOUR-byte chain, else of the
+// THREE-byte chain.
 #include "zg_internal.h"
 
 #include <type_traits>
 
 #ifndef ZG_MATCH_STEPS
 #define ZG_MATCH_STEPS 12
-#endif
-#ifndef ZG_LO_STEPS
-#define ZG_LO_STEPS 8
 #endif
 
 namespace zg {
@@ -49,6 +45,10 @@ __device__ __forceinline__ uint32_t key_hash(uint32_t lo, uint32_t hi);
 template <>
 __device__ __forceinline__ uint32_t key_hash<3>(uint32_t lo, uint32_t) {
     return (lo & 0x00FFFFFFu) * 0x9E3779B1u;
+}
+template <>
+__device__ __forceinline__ uint32_t key_hash<4>(uint32_t lo, uint32_t) {
+    return lo * 0x9E3779B1u;
 }
 template <>
 __device__ __forceinline__ uint32_t key_hash<5>(uint32_t lo, uint32_t hi) {
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t *__restrict__ data, 
 // A segment walks `window` positions above and below the seg_len ones it owns; the host picks seg_len so that
 // the waves of a launch fill the machine a whole number of times.
 #ifndef ZG_IDX_GROUP
-#define ZG_IDX_GROUP 4
+#define ZG_IDX_GROUP 16
 #endif
 constexpr uint32_t kIdxGroup = ZG_IDX_GROUP;         // batches of 64 positions handled together
 constexpr uint32_t kIdxSpan = 64 * kIdxGroup;
@@ -424,21 +424,22 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_li
     if (__any(violated) && lane == 0) atomicOr(status, 2u);
 }
 
-// One workgroup (one wave) per segment and key length: blockIdx.y selects the five-byte or the three-byte
-// index, so that both are built by one launch and share the machine.
+// One workgroup (one wave) per segment and key length: blockIdx.y selects the key length, so that all the
+// indexes of a call are built by one launch and share the machine.
 __global__ __launch_bounds__(64) void k_index_r(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
-                                                 uint64_t r1, uint64_t far_lo, uint32_t window, int key_a, int key_b,
-                                                 uint16_t *__restrict__ far_a, uint16_t *__restrict__ next_a,
-                                                 uint16_t *__restrict__ far_b, uint16_t *__restrict__ next_b,
+                                                 uint64_t r1, uint64_t far_lo, uint32_t window, IndexSet set,
                                                  uint64_t base, uint32_t *status, uint64_t iso_first,
                                                  uint32_t iso_bytes, uint32_t seg_len) {
     __shared__ uint32_t s_head[kIdxRBuckets];  // position + 1, 0 = empty
     __shared__ uint32_t s_link[kIdxSpan];      // distance to the successor, positions of the current group
-    const int key = blockIdx.y == 0 ? key_a : key_b;
-    uint16_t *far = blockIdx.y == 0 ? far_a : far_b;
-    uint16_t *next = blockIdx.y == 0 ? next_a : next_b;
+    const int key = set.key[blockIdx.y];
+    uint16_t *far = set.far[blockIdx.y];
+    uint16_t *next = set.next[blockIdx.y];
     if (key == 5)
         index_r_segment<5>(s_head, s_link, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base,
+                           status, iso_first, iso_bytes);
+    else if (key == 4)
+        index_r_segment<4>(s_head, s_link, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base,
                            status, iso_first, iso_bytes);
     else
         index_r_segment<3>(s_head, s_link, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base,
@@ -495,27 +496,27 @@ static hipError_t launch_index_slow(const uint8_t *data, uint64_t n_view, uint64
     return hipGetLastError();
 }
 
-// key_b == 0: one index only
 hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint64_t r1, uint64_t far_lo,
-                        uint32_t window, int key_a, uint16_t *far_a, uint16_t *next_a, int key_b, uint16_t *far_b,
-                        uint16_t *next_b, uint64_t base, uint32_t *status, bool safe, uint64_t iso_first,
-                        uint32_t iso_bytes, hipStream_t s) {
-    if (r1 <= r0) return hipSuccess;
+                        uint32_t window, const IndexSet &set, uint64_t base, uint32_t *status, bool safe,
+                        uint64_t iso_first, uint32_t iso_bytes, hipStream_t s) {
+    if (r1 <= r0 || set.n == 0) return hipSuccess;
     const bool brute = window < 2048 || n_view < 64;
     if (brute || (safe && !iso_bytes)) {  // the conservative variant has no notion of isolated slots
-        for (int which = 0; which < (key_b ? 2 : 1); which++) {
-            const int key = which ? key_b : key_a;
-            uint16_t *far = which ? far_b : far_a, *next = which ? next_b : next_a;
+        for (uint32_t which = 0; which < set.n; which++) {
+            const int key = set.key[which];
+            uint16_t *far = set.far[which], *next = set.next[which];
             const hipError_t e =
                 key == 5 ? launch_index_slow<5>(data, n_view, r0, r1, far_lo, window, far, next, base, brute, iso_first,
                                                 iso_bytes, s)
-                         : launch_index_slow<3>(data, n_view, r0, r1, far_lo, window, far, next, base, brute, iso_first,
-                                                iso_bytes, s);
+                : key == 4 ? launch_index_slow<4>(data, n_view, r0, r1, far_lo, window, far, next, base, brute,
+                                                  iso_first, iso_bytes, s)
+                           : launch_index_slow<3>(data, n_view, r0, r1, far_lo, window, far, next, base, brute,
+                                                  iso_first, iso_bytes, s);
             if (e != hipSuccess) return e;
         }
         return hipSuccess;
     }
-    const uint32_t ny = key_b ? 2u : 1u;
+    const uint32_t ny = set.n;
     // Segment length.  A wave walks its segment plus `reach` positions on either side, and the LDS table lets
     // four waves share a CU.  Small inputs are cut so that one launch fills the machine once; large ones into
     // segments of kIdxSegCap, short enough for waves on cheap and on costly data (long runs of one byte make
@@ -526,13 +527,13 @@ hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint6
         cus = 256;
     const uint64_t slots = 4ull * (uint64_t)cus, n_pos = r1 - r0;
     const uint64_t reach = iso_bytes && iso_bytes < window ? iso_bytes : window;
-    const uint64_t cap = reach <= 4096 ? 4ull * kIdxSegCap : kIdxSegCap;
+    const uint64_t cap = reach <= 4096 ? 8ull * kIdxSegCap : kIdxSegCap;  // isolated records are all alike
     uint64_t seg_len = (n_pos * ny + slots - 1) / slots;
     seg_len = (seg_len + kIdxSpan - 1) & ~(uint64_t)(kIdxSpan - 1);
     seg_len = seg_len < kIdxSegMin ? kIdxSegMin : (seg_len > cap ? cap : seg_len);
     const uint64_t nseg = (n_pos + seg_len - 1) / seg_len;
-    hipLaunchKernelGGL(k_index_r, dim3((uint32_t)nseg, ny), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, key_a,
-                       key_b, far_a, next_a, far_b, next_b, base, status, iso_first, iso_bytes, (uint32_t)seg_len);
+    hipLaunchKernelGGL(k_index_r, dim3((uint32_t)nseg, ny), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, set,
+                       base, status, iso_first, iso_bytes, (uint32_t)seg_len);
     return hipGetLastError();
 }
 
@@ -544,9 +545,8 @@ uint64_t index_lookback(uint32_t window) { return window; }
 // are staged in LDS; the threads then claim positions of the tile one by one.
 // ---------------------------------------------------------------------------
 // Geometry of a match workgroup: positions per tile, positions of window staged before them, threads, and how
-// many parked level-2 walks it can hold.  GeomStream is the general one; GeomRecord serves isolated chunks
-// (records) of at most 4 KiB, whose window is the record itself -- a twelfth of the LDS, so that many records
-// are resident per CU.
+// many parked level-2 walks it can hold.  GeomStream is the general one; GeomRecord serves isolated chunks (records) of at most 4 KiB, whose window is
+// the record itself -- a twelfth of the LDS, so that many records are resident per CU.
 template <uint32_t kTileT, uint32_t kWinT, uint32_t kThreadsT, uint32_t kParkedT>
 struct MatchGeom {
     static constexpr uint32_t tile = kTileT, win = kWinT, threads = kThreadsT, parked = kParkedT;
@@ -577,6 +577,21 @@ __device__ __forceinline__ uint32_t lds_lcp(const uint8_t *lds, uint32_t so, uin
     return m < cap ? m : cap;
 }
 
+// copies links [w0, w0 + nlinks) of the view into LDS
+__device__ __forceinline__ void stage_links(const uint16_t *__restrict__ next, uint64_t base, uint64_t w0,
+                                            uint32_t nlinks, uint16_t *s_next, uint32_t tid, uint32_t nthreads) {
+    const uint16_t *src = next + (w0 - base);
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(s_next);
+        const uint32_t nv = nlinks >> 3;
+        for (uint32_t i = tid; i < nv; i += nthreads) d4[i] = s4[i];
+        for (uint32_t i = (nv << 3) + tid; i < nlinks; i += nthreads) s_next[i] = src[i];
+    } else {
+        for (uint32_t i = tid; i < nlinks; i += nthreads) s_next[i] = src[i];
+    }
+}
+
 // copies bytes [w0, w0 + nbytes) and links [w0, w0 + nlinks) of the view into LDS
 __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ data, const uint16_t *__restrict__ next,
                                            uint64_t base, uint64_t w0, uint32_t nbytes, uint32_t nlinks,
@@ -593,18 +608,7 @@ __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ data, con
         for (uint32_t i = tid; i < nbytes; i += nthreads) s_data[i] = data[w0 + i];
     }
     for (uint32_t i = nbytes + tid; i < nbytes + 16 && i < data_cap; i += nthreads) s_data[i] = 0;
-    {
-        const uint16_t *src = next + (w0 - base);
-        if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-            const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
-            uint4 *d4 = reinterpret_cast<uint4 *>(s_next);
-            const uint32_t nv = nlinks >> 3;
-            for (uint32_t i = tid; i < nv; i += nthreads) d4[i] = s4[i];
-            for (uint32_t i = (nv << 3) + tid; i < nlinks; i += nthreads) s_next[i] = src[i];
-        } else {
-            for (uint32_t i = tid; i < nlinks; i += nthreads) s_next[i] = src[i];
-        }
-    }
+    stage_links(next, base, w0, nlinks, s_next, tid, nthreads);
 }
 
 template <class G>
@@ -616,8 +620,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                                                           const uint16_t *__restrict__ far,
                                                           const uint16_t *__restrict__ next, uint64_t base,
                                                           uint32_t *__restrict__ match,
-                                                          const uint16_t *__restrict__ far_lo,
-                                                          uint2 *__restrict__ open_list,
+                                                          uint32_t *__restrict__ open_list,
                                                           uint32_t *__restrict__ open_cnt) {
     // one LDS image: bytes first (so that byte reads need no base add), links behind them
     __shared__ __attribute__((aligned(16))) uint8_t s_mem[G::data_lds + 2 * G::next_lds];
@@ -666,8 +669,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     const uint32_t pbase = (uint32_t)(t0 - w0);  // LDS offset of tile position 0
     const uint32_t lo_off = (uint32_t)(wlo - w0); // LDS offset of the lowest candidate there is
     const uint16_t *far_t = far + (t0 - base);
-    const uint16_t *far_lo_t = emit_term ? far_lo + (t0 - base) : far_t;
-    uint2 *open_t = open_list + (uint64_t)bid * G::tile;
+    uint32_t *open_t = open_list + (uint64_t)bid * G::tile;
     uint32_t *match_t = match + (t0 - base);
     const uint64_t tail_room = ce - t0;  // bytes from tile position 0 to the end of the chunk
     const uint32_t tail_room32 = tail_room < 0x7FFFFFFFull ? (uint32_t)tail_room : 0x7FFFFFFFu;
@@ -715,8 +717,6 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     bool has_pos = false;  // a position is loaded and its result is not yet written
     uint32_t nxt_idx = atomicAdd(&s_counter, 1u);
     uint32_t nxt_far = nxt_idx < tn ? far_t[nxt_idx] : 0u;
-    uint32_t nxt_flo = (emit_term && nxt_idx < tn) ? far_lo_t[nxt_idx] : 0u;  // level-2 entry of that position
-    uint32_t cur_flo = 0;
 
     for (;;) {
 #pragma unroll
@@ -839,13 +839,13 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                 // Order matters for the memory counter, which retires in issue order: first take the values
                 // prefetched by the previous visit (nothing younger is in flight, so this costs no wait), then
                 // issue this visit's stores and, last, the loads for the next position.
-                uint32_t fd = nxt_far, flo = nxt_flo;
-                asm volatile("" : "+v"(fd), "+v"(flo));
+                uint32_t fd = nxt_far;
+                asm volatile("" : "+v"(fd));
                 if (has_pos) {
                     match_t[idx] = best ? ((best << 16) | bestd) : 0u;
-                    if (best == 0u && cur_flo != 0u) {  // still open, and level 2 has candidates for it
+                    if (best == 0u && emit_term) {  // still open: handed on to level 2
                         const uint32_t slot = atomicAdd(&s_nopen, 1u);
-                        open_t[slot] = make_uint2(idx | (termd << 16), cur_flo);
+                        open_t[slot] = idx | (termd << 16);
                     }
                 }
                 has_pos = false;
@@ -853,7 +853,6 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                     ft = false;  // no positions left
                 } else {
                     idx = nxt_idx;
-                    cur_flo = emit_term ? flo : 0u;
                     const uint32_t remain32 = tail_room32 - idx;  // bytes to the end of the chunk, saturated
                     cap = remain32 < max_len - 1 ? remain32 : max_len - 1;
                     best = 0;
@@ -880,7 +879,6 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                     nxt_idx = atomicAdd(&s_counter, 1u);
                     const uint32_t ni = nxt_idx < tn ? nxt_idx : 0u;  // unconditional loads: tn >= 1 here
                     nxt_far = far_t[ni];
-                    nxt_flo = far_lo_t[ni];
                 }
             }
         } else if (n_fetch == 0 && n_head == 0 && n_eval == 0) {
@@ -894,30 +892,222 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
 }
 
 // Level 2: the positions level 1 handed on, as a per-tile list of (tile position | distance of the level-1
-// candidate that ended the search << 16, distance of the farthest three-byte chain member).  Candidates at or
-// below the search-ending distance are not looked at.  Every candidate in reach matches at most four bytes,
-// so four bytes of it decide everything.  Positions without a result keep the 0 level 1 wrote.
-//
-// A walk ends at the first four-byte agreement, which a position with a frequent first three bytes and a rare
-// fourth may reach only after thousands of chain members -- one lane busy while the rest of the tile has
-// finished.  A walk that has used up its step budget is therefore parked, and afterwards finished by a whole
-// wave: the 64 lanes compare the window from the walk's current candidate upward directly with the position's
-// four bytes, which finds the same "first agreement" in a bounded number of passes.
-#ifndef ZG_LO_BUDGET
-#define ZG_LO_BUDGET 256
+// candidate that ended the search << 16).  Candidates at or below that distance are not looked at.  Every
+// candidate in reach matches at most four bytes, so the answer is the farthest candidate with four common bytes
+// (more than five positions back: at distance four or five such a candidate ends the search instead), else
+// the farthest with three.  Both are the first TRUE member -- hash collisions aside -- of a chain: the
+// four-byte chain from far4[pos], then the three-byte chain from far3[pos], so the walks are a few steps long.
+// The tile's bytes and window are staged in LDS as in level 1; the links of the four-byte index share their LDS
+// space with those of the three-byte index, which replace them for a second pass over the positions the first
+// pass could not settle (marked in the list itself).
+constexpr uint32_t kOpenAgain = 0x80000000u;  // list entry: four-byte chain exhausted, three-byte chain to be walked
+#ifndef ZG_LO_STEPS
+#define ZG_LO_STEPS 4
 #endif
+#ifndef ZG_LO_FETCH_BATCH
+#define ZG_LO_FETCH_BATCH 8
+#endif
+#ifndef ZG_LO_BUDGET
+#define ZG_LO_BUDGET 64
+#endif
+
+// One pass of level 2 over a tile's list.  Walk lengths are very uneven (a rare key that shares its bucket with
+// a frequent one walks through all of the latter's members), so, as in level 1, lanes claim list entries from
+// an LDS counter whenever they finish one, and all lanes run branch-free steps in between.
+//   kPass 1: four-byte chain; the first candidate more than max(5, excl) back that agrees in four bytes is the
+//            answer; entries left without one are marked kOpenAgain.
+//   kPass 2: three-byte chain, marked entries only; the first candidate good for anything decides.
+#ifdef ZG_DEBUG_COUNTERS
+__device__ unsigned long long g_dbg[64];
+extern "C" int zg_debug_counters(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg));
+}
+#endif
+// A walk that has used up its step budget (a rare key sharing its bucket with a frequent one: thousands of
+// members, one lane busy while the rest of the tile has finished) is parked -- (list index, cursor) in s_park --
+// and finished afterwards by a whole wave: the 64 lanes compare the window from the cursor upward directly
+// with the position's bytes, which finds the same first agreement in a bounded number of passes.
+template <int kPass, uint32_t kParked, uint32_t kThreads>
+__device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s_next, uint32_t *s_counter,
+                                        uint32_t *s_nparked, uint32_t *s_park, uint32_t *open_t,
+                                        const uint32_t *far_t, uint32_t n_open, uint32_t *match_t, uint32_t pbase,
+                                        uint32_t tail_room32, uint32_t min_len, uint32_t max_len) {
+    constexpr int kSteps = ZG_LO_STEPS;
+    constexpr uint32_t kFetchBatch = ZG_LO_FETCH_BATCH;
+    constexpr uint32_t kBudgetTrips = (ZG_LO_BUDGET + kSteps - 1) / kSteps;
+    uint32_t trips = 0;
+    bool hd = false, ft = true, has_pos = false;
+    uint32_t cur_i = 0, cur_e = 0, idx = 0, po = pbase, so = pbase, lim = 0, p0 = 0, excl = 0, res = 0;
+    uint32_t nxt_i = atomicAdd(s_counter, 1u);
+    uint32_t nxt_e = nxt_i < n_open ? open_t[nxt_i] : 0u;
+    uint32_t nxt_f = nxt_i < n_open ? far_t[nxt_i] : 0u;
+    for (;;) {
+#pragma unroll
+        for (int step = 0; step < kSteps; step++) {
+            const uint32_t d = po - so;
+            const uint32_t w = lds_ld4(s_data, so);
+            const uint32_t nx = s_next[so];
+            const bool stop_pre = d <= excl;
+            bool fin;
+            if (kPass == 1) {
+                const bool hit = w == p0;
+                res = (hd & !stop_pre & hit) ? ((4u << 16) | d) : res;
+                fin = hd & (stop_pre | hit | (nx == 0u));
+            } else {
+                const uint32_t x = w ^ p0;
+                uint32_t m = ((uint32_t)__ffs((int)x) - 1u) >> 3;  // equal leading bytes; huge when all four agree
+                m = m < lim ? m : lim;
+                const bool good = m >= min_len;
+                const bool ends = d <= m + 1u;  // the growing match reaches pos: nothing recorded
+                res = (hd & !stop_pre & good & !ends) ? ((m << 16) | d) : res;
+                fin = hd & (stop_pre | good | (nx == 0u));
+            }
+#ifdef ZG_DEBUG_COUNTERS
+            if (hd) atomicAdd(&g_dbg[(kPass - 1) * 16 + (idx & 15)], 1ull);
+#endif
+            so += (hd & !fin) ? nx : 0u;
+            ft |= fin;
+            hd &= !fin;
+        }
+        trips += 1;
+        if (hd && trips >= kBudgetTrips) {
+            const uint32_t slot = atomicAdd(s_nparked, 1u);
+            if (slot < kParked) {
+                s_park[slot * 2 + 0] = cur_i;
+                s_park[slot * 2 + 1] = so;
+                hd = false;
+                ft = true;
+                has_pos = false;
+            } else {
+                trips = 0;  // no room: walk on
+            }
+        }
+        const uint32_t n_head = (uint32_t)__popcll(__ballot(hd));
+        const uint32_t n_fetch = (uint32_t)__popcll(__ballot(ft));
+        if (n_fetch >= kFetchBatch || (n_fetch != 0 && n_head == 0)) {
+            if (ft) {
+                // take the prefetched entry before anything younger is put in flight (see k_match)
+                uint32_t ex = nxt_e, ef = nxt_f;
+                asm volatile("" : "+v"(ex), "+v"(ef));
+                if (has_pos) {
+                    if (res)
+                        match_t[idx] = res;
+                    else if (kPass == 1)
+                        open_t[cur_i] = cur_e | kOpenAgain;
+                }
+                has_pos = false;
+                if (nxt_i >= n_open) {
+                    ft = false;  // nothing left to claim
+                } else {
+                    cur_i = nxt_i;
+                    cur_e = ex;
+                    idx = ex & 0xFFFFu;
+                    const uint32_t termd = (ex >> 16) & 0x1FFu;
+                    const uint32_t remain32 = tail_room32 - idx;
+                    const uint32_t cap = remain32 < max_len - 1 ? remain32 : max_len - 1;
+                    lim = cap < 4u ? cap : 4u;
+                    res = 0;
+                    trips = 0;
+                    // the reference searches only while pos < len - min_len, and records nothing below min_len
+                    const bool valid = remain32 > min_len && lim >= min_len && (kPass == 1 || (ex & kOpenAgain));
+                    const uint32_t fd = kPass == 1 ? (lim >= 4u ? (ef & 0xFFFFu) : 0u) : (ef >> 16);
+                    has_pos = valid;
+#ifdef ZG_DEBUG_COUNTERS
+                    if (valid) atomicAdd(&g_dbg[32 + (kPass - 1) * 16 + (idx & 15)], 1ull);
+#endif
+                    if (valid && fd != 0) {
+                        po = pbase + idx;
+                        so = po - fd;
+                        p0 = lds_ld4(s_data, po);
+                        excl = min_len > termd ? min_len : termd;  // candidates lie more than this below pos
+                        if (kPass == 1) excl = excl > 5u ? excl : 5u;  // four bytes at distance 4 or 5 end the search
+                        hd = true;
+                        ft = false;
+                    }
+                    nxt_i = atomicAdd(s_counter, 1u);
+                    const uint32_t ni = nxt_i < n_open ? nxt_i : 0u;  // unconditional loads: n_open >= 1 here
+                    nxt_e = open_t[ni];
+                    nxt_f = far_t[ni];
+                }
+            }
+        } else if (n_fetch == 0 && n_head == 0) {
+            break;  // no lane has anything left
+        }
+    }
+    __syncthreads();
+
+    // parked walks, dealt round-robin to the waves
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n_raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_nparked);
+    const uint32_t n_parked = n_raw < kParked ? n_raw : kParked;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t want_mask = (kPass == 1 || min_len >= 4u) ? 0xFFFFFFFFu : 0x00FFFFFFu;
+    for (uint32_t k = wave; k < n_parked; k += kThreads / 64) {
+        const uint32_t pi = s_park[k * 2 + 0], s_lo = s_park[k * 2 + 1];
+        const uint32_t pe = open_t[pi];
+        const uint32_t pidx = pe & 0xFFFFu, ptermd = (pe >> 16) & 0x1FFu;
+        const uint32_t ppo = pbase + pidx;
+        uint32_t pexcl = min_len > ptermd ? min_len : ptermd;  // candidates lie more than this below pos
+        if (kPass == 1) pexcl = pexcl > 5u ? pexcl : 5u;
+        const uint32_t s_hi = ppo - pexcl;                      // one past the last candidate
+        const uint32_t pp0 = lds_ld4(s_data, ppo);
+        uint32_t hit = 0xFFFFFFFFu, hit_x = 0;                  // lowest candidate agreeing in the wanted bytes
+        for (uint32_t b0 = s_lo; b0 < s_hi; b0 += 256) {
+            const uint32_t b = b0 + lane * 4;
+            const uint32_t wa = lds_ld4(s_data, b), wb = lds_ld4(s_data, b + 4);
+            uint32_t h = 0xFFFFFFFFu, hx = 0;
+#pragma unroll
+            for (int j = 3; j >= 0; j--) {
+                const uint32_t v = j == 0 ? wa : __builtin_amdgcn_alignbyte(wb, wa, (uint32_t)j);
+                const uint32_t x = v ^ pp0;
+                if (b + (uint32_t)j < s_hi && (x & want_mask) == 0u) {
+                    h = b + (uint32_t)j;
+                    hx = x;
+                }
+            }
+            // lowest hit over the wave: lanes hold ascending, disjoint ranges
+            const uint64_t mh = __ballot(h != 0xFFFFFFFFu);
+            if (mh) {
+                const int src = __ffsll((unsigned long long)mh) - 1;
+                hit = (uint32_t)__shfl((int)h, src);
+                hit_x = (uint32_t)__shfl((int)hx, src);
+                break;
+            }
+        }
+        if (lane == 0) {
+            if (kPass == 1) {
+                if (hit != 0xFFFFFFFFu)
+                    match_t[pidx] = (4u << 16) | (ppo - hit);
+                else
+                    open_t[pi] = pe | kOpenAgain;
+            } else if (hit != 0xFFFFFFFFu) {
+                const uint32_t remain32 = tail_room32 - pidx;
+                const uint32_t cap = remain32 < max_len - 1 ? remain32 : max_len - 1;
+                const uint32_t plim = cap < 4u ? cap : 4u;
+                uint32_t m = hit_x ? ((uint32_t)__builtin_ctz(hit_x) >> 3) : 4u;
+                m = m < plim ? m : plim;
+                const uint32_t d = ppo - hit;
+                if (d > m + 1u) match_t[pidx] = (m << 16) | d;  // else the growing match reaches pos
+            }
+        }
+    }
+}
 
 template <class G>
 __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restrict__ data, uint64_t first,
                                                              uint64_t end, uint64_t chunk_bytes,
                                                              const uint32_t *__restrict__ clen, uint32_t isolated,
                                                              uint32_t c0, uint32_t tiles_per_chunk, MatchParams mp,
-                                                             const uint16_t *__restrict__ next, uint64_t base,
+                                                             const uint16_t *__restrict__ far4,
+                                                             const uint16_t *__restrict__ next4,
+                                                             const uint16_t *__restrict__ far3,
+                                                             const uint16_t *__restrict__ next3, uint64_t base,
                                                              uint32_t *__restrict__ match,
-                                                             const uint2 *__restrict__ open_list,
+                                                             uint32_t *__restrict__ open_list,
+                                                             uint32_t *__restrict__ open_far,
                                                              const uint32_t *__restrict__ open_cnt) {
     __shared__ __attribute__((aligned(16))) uint8_t s_mem[G::data_lds + 2 * G::next_lds];
-    __shared__ uint32_t s_park[G::parked * 3];  // tile position | end distance << 16, candidate | best << 16, best distance
+    __shared__ uint32_t s_park[G::parked * 2];  // list index, cursor
     __shared__ uint32_t s_counter;              // next unclaimed list entry
     __shared__ uint32_t s_nparked;
     uint8_t *const s_data = s_mem;
@@ -938,193 +1128,73 @@ __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restri
     const uint64_t w1 = (t1 + 8 < ce) ? t1 + 8 : ce;  // four bytes of look-ahead are all this level reads
     const uint32_t nbytes = (uint32_t)(w1 - w0);
     const uint32_t nlinks = (uint32_t)(t1 - w0);
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint2 *open_t = open_list + (uint64_t)bid * G::tile;
+    const uint32_t tid = threadIdx.x;
+    uint32_t *open_t = open_list + (uint64_t)bid * G::tile;
+    uint32_t *far_t = open_far + (uint64_t)bid * G::tile;
     uint32_t *match_t = match + (t0 - base);
     if (tid == 0) {
         s_counter = 0;
         s_nparked = 0;
     }
-    stage_tile(data, next, base, w0, nbytes, nlinks, s_data, s_next, tid, G::threads, G::data_lds);
+    // the chain entries of the listed positions, beside the list: far4 | far3 << 16
+    {
+        const uint16_t *far4_t = far4 + (t0 - base), *far3_t = far3 + (t0 - base);
+        for (uint32_t i = tid; i < n_open; i += G::threads) {
+            const uint32_t idx = open_t[i] & 0xFFFFu;
+            far_t[i] = (uint32_t)far4_t[idx] | ((uint32_t)far3_t[idx] << 16);
+        }
+    }
+    stage_tile(data, next4, base, w0, nbytes, nlinks, s_data, s_next, tid, G::threads, G::data_lds);
     __syncthreads();
 
-    const uint32_t min_len = mp.min_len, max_len = mp.max_len;
     const uint32_t pbase = (uint32_t)(t0 - w0);
     const uint64_t tail_room = ce - t0;
     const uint32_t tail_room32 = tail_room < 0x7FFFFFFFull ? (uint32_t)tail_room : 0x7FFFFFFFu;
-
-    constexpr int kSteps = ZG_LO_STEPS;
-#ifndef ZG_LO_FETCH_BATCH
-#define ZG_LO_FETCH_BATCH 4
-#endif
-    constexpr uint32_t kFetchBatch = ZG_LO_FETCH_BATCH;
-    constexpr uint32_t kBudgetTrips = (ZG_LO_BUDGET + kSteps - 1) / kSteps;
-    bool hd = false, ft = true;  // walking / waiting to retire and claim
-    uint32_t idx = 0, po = pbase, so = pbase, lim = 0, best = 0, bestd = 0, p0 = 0, termd = 0, trips = 0;
-    bool has_pos = false;
-    uint32_t nxt_i = atomicAdd(&s_counter, 1u);
-    uint2 nxt_ent = nxt_i < n_open ? open_t[nxt_i] : make_uint2(0u, 0u);
-
-    for (;;) {
-#pragma unroll
-        for (int step = 0; step < kSteps; step++) {
-            const uint32_t d = po - so;
-            const uint32_t w = lds_ld4(s_data, so);
-            const uint32_t nx = s_next[so];
-            const uint32_t x = w ^ p0;
-            uint32_t m = ((uint32_t)__ffs((int)x) - 1u) >> 3;  // equal leading bytes; huge when all four agree
-            m = m < lim ? m : lim;
-            const bool stop_pre = (d <= min_len) | (d <= termd);  // loop guard / level-1 end of search
-            const bool good = m >= min_len;
-            const bool ends = good & (d <= m + 1u);               // the growing match reaches pos
-            const bool take = hd & !stop_pre & good & !ends & (m > best);
-            best = take ? m : best;
-            bestd = take ? d : bestd;
-            const bool fin = hd & (stop_pre | ends | (take & (m == lim)) | (nx == 0u));
-            so += (hd & !fin) ? nx : 0u;
-            ft |= fin;
-            hd &= !fin;
-        }
-        // park walks that have run long (only those still looking for a fourth byte)
-        trips += 1;
-        if (hd && trips >= kBudgetTrips && lim == 4u) {
-            const uint32_t slot = atomicAdd(&s_nparked, 1u);
-            if (slot < G::parked) {
-                s_park[slot * 3 + 0] = idx | (termd << 16);
-                s_park[slot * 3 + 1] = so | (best << 16);
-                s_park[slot * 3 + 2] = bestd;
-                hd = false;
-                ft = true;
-                has_pos = false;
-            } else {
-                trips = 0;  // no room: walk on
-            }
-        }
-        const uint32_t n_head = (uint32_t)__popcll(__ballot(hd));
-        const uint32_t n_fetch = (uint32_t)__popcll(__ballot(ft));
-        if (n_fetch >= kFetchBatch || (n_fetch != 0 && n_head == 0)) {
-            if (ft) {
-                // take the prefetched entry before anything younger is put in flight (see k_match)
-                uint32_t ex = nxt_ent.x, ey = nxt_ent.y;
-                asm volatile("" : "+v"(ex), "+v"(ey));
-                if (has_pos && best) match_t[idx] = (best << 16) | bestd;
-                has_pos = false;
-                if (nxt_i >= n_open) {
-                    ft = false;  // nothing left to claim
-                } else {
-                    idx = ex & 0xFFFFu;
-                    termd = ex >> 16;
-                    const uint32_t fd = ey;
-                    const uint32_t remain32 = tail_room32 - idx;
-                    const uint32_t cap = remain32 < max_len - 1 ? remain32 : max_len - 1;
-                    lim = cap < 4u ? cap : 4u;
-                    best = 0;
-                    bestd = 0;
-                    trips = 0;
-                    has_pos = true;
-                    if (fd != 0 && remain32 > min_len && lim >= min_len) {
-                        po = pbase + idx;
-                        so = po - fd;
-                        p0 = lds_ld4(s_data, po);
-                        hd = true;
-                        ft = false;
-                    }
-                    nxt_i = atomicAdd(&s_counter, 1u);
-                    nxt_ent = open_t[nxt_i < n_open ? nxt_i : 0u];  // unconditional load: n_open >= 1 here
-                }
-            }
-        } else if (n_fetch == 0 && n_head == 0) {
-            break;  // no lane has anything left
-        }
+    lo_pass<1, G::parked, G::threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open, match_t,
+                                      pbase, tail_room32, mp.min_len, mp.max_len);
+    __syncthreads();  // also orders the list entries written in pass 1 before their readers in pass 2
+    if (tid == 0) {
+        s_counter = 0;
+        s_nparked = 0;
     }
+    stage_links(next3, base, w0, nlinks, s_next, tid, G::threads);
     __syncthreads();
-
-    // parked walks, dealt round-robin to the waves
-    const uint32_t n_raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_nparked);
-    const uint32_t n_parked = n_raw < G::parked ? n_raw : G::parked;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    for (uint32_t e = wave; e < n_parked; e += G::threads / 64) {
-        const uint32_t e0 = s_park[e * 3 + 0], e1 = s_park[e * 3 + 1], e2 = s_park[e * 3 + 2];
-        const uint32_t pidx = e0 & 0xFFFFu, ptermd = e0 >> 16;
-        const uint32_t s_lo = e1 & 0xFFFFu, pbest = e1 >> 16, pbestd = e2;
-        const uint32_t ppo = pbase + pidx;
-        const uint32_t excl = min_len > ptermd ? min_len : ptermd;  // candidates lie more than this below pos
-        const uint32_t s_hi = ppo - excl;                           // one past the last candidate
-        const uint32_t pp0 = lds_ld4(s_data, ppo);
-        uint32_t first4 = 0xFFFFFFFFu, first3 = 0xFFFFFFFFu;        // lowest candidates agreeing in 4 / 3 bytes
-        for (uint32_t b0 = s_lo; b0 < s_hi; b0 += 256) {
-            const uint32_t b = b0 + lane * 4;
-            const uint32_t wa = lds_ld4(s_data, b), wb = lds_ld4(s_data, b + 4);
-            uint32_t h4 = 0xFFFFFFFFu, h3 = 0xFFFFFFFFu;
-#pragma unroll
-            for (int j = 3; j >= 0; j--) {
-                const uint32_t v = j == 0 ? wa : __builtin_amdgcn_alignbyte(wb, wa, (uint32_t)j);
-                const uint32_t x = v ^ pp0;
-                const bool in = b + (uint32_t)j < s_hi;
-                if (in && x == 0u) h4 = b + (uint32_t)j;
-                if (in && (x & 0x00FFFFFFu) == 0u) h3 = b + (uint32_t)j;
-            }
-            // lowest hit over the wave: lanes hold ascending, disjoint ranges
-            const uint64_t m3 = __ballot(h3 != 0xFFFFFFFFu);
-            if (m3 && first3 == 0xFFFFFFFFu)
-                first3 = (uint32_t)__shfl((int)h3, __ffsll((unsigned long long)m3) - 1);
-            const uint64_t m4 = __ballot(h4 != 0xFFFFFFFFu);
-            if (m4) {
-                first4 = (uint32_t)__shfl((int)h4, __ffsll((unsigned long long)m4) - 1);
-                break;
-            }
-        }
-        if (lane == 0) {
-            uint32_t rl = 0, rd = 0;
-            const uint32_t d4 = ppo - first4, d3 = ppo - first3;
-            if (first4 != 0xFFFFFFFFu && d4 >= 6u) {  // four bytes at distance 4 or 5 end the search instead
-                rl = 4;
-                rd = d4;
-            } else if (min_len <= 3u) {
-                if (pbest == 3u) {  // found farther back by the walk
-                    rl = 3;
-                    rd = pbestd;
-                } else if (first3 != 0xFFFFFFFFu && first3 != first4 && d3 >= 5u) {
-                    rl = 3;
-                    rd = d3;
-                }
-            }
-            if (rl) match_t[pidx] = (rl << 16) | rd;
-        }
-    }
+    lo_pass<2, G::parked, G::threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open, match_t,
+                                      pbase, tail_room32, mp.min_len, mp.max_len);
 }
 
 hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, uint32_t rec_min,
                         const uint16_t *far, const uint16_t *next, uint64_t base, uint32_t *match,
-                        const uint16_t *far_lo, uint2 *open_list, uint32_t *open_cnt, hipStream_t s) {
+                        uint32_t *open_list, uint32_t *open_cnt, hipStream_t s) {
     if (c1 <= c0) return hipSuccess;
     const uint32_t tpc = match_tiles_per_chunk(g);
     const uint64_t nblocks = (uint64_t)(c1 - c0) * tpc;
     if (match_tile_positions(g) == kMatchRecordTile)
         hipLaunchKernelGGL(k_match<GeomRecord>, dim3((uint32_t)nblocks), dim3(GeomRecord::threads), 0, s, g.data,
                            g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, rec_min,
-                           far_lo ? 1u : 0u, far, next, base, match, far_lo, open_list, open_cnt);
+                           open_list ? 1u : 0u, far, next, base, match, open_list, open_cnt);
     else
         hipLaunchKernelGGL(k_match<GeomStream>, dim3((uint32_t)nblocks), dim3(GeomStream::threads), 0, s, g.data,
                            g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, rec_min,
-                           far_lo ? 1u : 0u, far, next, base, match, far_lo, open_list, open_cnt);
+                           open_list ? 1u : 0u, far, next, base, match, open_list, open_cnt);
     return hipGetLastError();
 }
 
-hipError_t launch_match_lo(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *next,
-                           uint64_t base, uint32_t *match, const uint2 *open_list, const uint32_t *open_cnt,
+hipError_t launch_match_lo(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *far4,
+                           const uint16_t *next4, const uint16_t *far3, const uint16_t *next3, uint64_t base,
+                           uint32_t *match, uint32_t *open_list, uint32_t *open_far, const uint32_t *open_cnt,
                            hipStream_t s) {
     if (c1 <= c0) return hipSuccess;
     const uint32_t tpc = match_tiles_per_chunk(g);
     const uint64_t nblocks = (uint64_t)(c1 - c0) * tpc;
     if (match_tile_positions(g) == kMatchRecordTile)
         hipLaunchKernelGGL(k_match_lo<GeomRecord>, dim3((uint32_t)nblocks), dim3(GeomRecord::threads), 0, s, g.data,
-                           g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, next, base, match,
-                           open_list, open_cnt);
+                           g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, far4, next4, far3, next3,
+                           base, match, open_list, open_far, open_cnt);
     else
         hipLaunchKernelGGL(k_match_lo<GeomStream>, dim3((uint32_t)nblocks), dim3(GeomStream::threads), 0, s, g.data,
-                           g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, next, base, match,
-                           open_list, open_cnt);
+                           g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, far4, next4, far3, next3,
+                           base, match, open_list, open_far, open_cnt);
     return hipGetLastError();
 }
 
