@@ -685,6 +685,9 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
 #ifndef ZG_SWITCH_TRIPS
 #define ZG_SWITCH_TRIPS 4
 #endif
+#ifndef ZG_SWITCH_EVERY
+#define ZG_SWITCH_EVERY 4
+#endif
 #ifndef ZG_SWITCH_REMAIN
 #define ZG_SWITCH_REMAIN 256
 #endif
@@ -713,6 +716,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     uint32_t noff = 0;    // minus the chain offset o
     uint32_t st = 0;      // o | largest distance tested for a search-ending candidate << 8 | trips since the claim << 17
     bool need_sw = false; // best has grown since the chain was chosen
+    uint32_t round = 0;   // trips of the workgroup's loop (uniform)
     uint32_t termd = 0;                        // distance of the candidate that ended the search, if one did
     bool has_pos = false;  // a position is loaded and its result is not yet written
     uint32_t nxt_idx = atomicAdd(&s_counter, 1u);
@@ -793,7 +797,8 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
         }
         // ---- long walks: move to the chain that the best length so far selects ----
         st += 1u << 17;
-        if (kSwitchTrips != 0) {
+        ++round;
+        if (kSwitchTrips != 0 && (round & (ZG_SWITCH_EVERY - 1)) == 0) {  // looked at every few trips only
             // worth it when the chain walked now is dense: at the rate of members per byte seen since the best
             // candidate, more than kSwitchRemain steps are left before the position
             const uint32_t trips = st >> 17, dcur = po - so - noff, cov = bestd - dcur;
