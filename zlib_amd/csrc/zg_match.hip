@@ -205,8 +205,14 @@ constexpr uint32_t kIdxSpan = 64 * kIdxGroup;
 #define ZG_IDX_DEPTH 1
 #endif
 constexpr uint32_t kIdxDepth = ZG_IDX_DEPTH;         // groups whose keys are in flight
-constexpr uint32_t kIdxSegMin = 16u << 10, kIdxSegCap = 128u << 10;  // positions owned by one k_index_r wave
-constexpr uint32_t kIdxRBits = 13;
+#ifndef ZG_IDX_CAP_KB
+#define ZG_IDX_CAP_KB 256
+#endif
+constexpr uint32_t kIdxSegMin = 16u << 10, kIdxSegCap = ZG_IDX_CAP_KB << 10;  // positions owned by one k_index_r wave
+#ifndef ZG_IDX_BITS
+#define ZG_IDX_BITS 13
+#endif
+constexpr uint32_t kIdxRBits = ZG_IDX_BITS;
 constexpr uint32_t kIdxRBuckets = 1u << kIdxRBits;
 
 template <int K>
@@ -334,17 +340,21 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_li
         }
         if (kLook) {
             if (__any(hop)) {
-                // members of the batch below p - window: follow the batch's links upward
+                // members of the batch below p - window: follow the batch's links upward.  All the reads of a
+                // round are issued before any is used (the index is wrapped into the group for lanes that have
+                // arrived), so a round costs one LDS latency.
                 for (uint32_t guard = 0; guard < 64; ++guard) {
+                    uint32_t l[kIdxGroup];
+#pragma unroll
+                    for (int k = 0; k < (int)kIdxGroup; k++) l[k] = s_link[(e[k] - qg) & (kIdxSpan - 1u)];
                     bool more = false;
 #pragma unroll
                     for (int k = 0; k < (int)kIdxGroup; k++) {
                         const uint32_t ql = look_pos(qg, k);
-                        if (lv[k] && e[k] < ql - window) {
-                            const uint32_t l = s_link[e[k] - qg];
-                            e[k] = l ? e[k] + l : ql;
-                            more |= e[k] < ql - window;
-                        }
+                        const bool go = lv[k] && e[k] < ql - window;
+                        const uint32_t en = l[k] ? e[k] + l[k] : ql;
+                        e[k] = go ? en : e[k];
+                        more |= go && en < ql - window;
                     }
                     if (!__any(more)) break;
                 }
@@ -518,16 +528,20 @@ hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint6
     }
     const uint32_t ny = set.n;
     // Segment length.  A wave walks its segment plus `reach` positions on either side, and the LDS table lets
-    // four waves share a CU.  Small inputs are cut so that one launch fills the machine once; large ones into
-    // segments of kIdxSegCap, short enough for waves on cheap and on costly data (long runs of one byte make
-    // every lane of a batch collide) to even out over several fillings.
+    // four waves share a CU (which keeps its LDS pipeline about 70 % busy: more waves would not help).  Small
+    // inputs are cut so that one launch fills the machine once; large ones into segments of kIdxSegCap, short
+    // enough for waves on cheap and on costly data (long runs of one byte make every lane of a batch collide)
+    // to even out over several fillings.
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         cus = 256;
     const uint64_t slots = 4ull * (uint64_t)cus, n_pos = r1 - r0;
     const uint64_t reach = iso_bytes && iso_bytes < window ? iso_bytes : window;
-    const uint64_t cap = reach <= 4096 ? 8ull * kIdxSegCap : kIdxSegCap;  // isolated records are all alike
+    // isolated records are all alike: long segments; otherwise kIdxSegCap, or half of it while that still
+    // leaves the machine no more than two fillings (the tail of the last filling then runs on emptier CUs)
+    uint64_t cap = reach <= 4096 ? 8ull * kIdxSegCap : kIdxSegCap;
+    if (reach > 4096 && n_pos * ny <= slots * kIdxSegCap) cap = kIdxSegCap / 2;
     uint64_t seg_len = (n_pos * ny + slots - 1) / slots;
     seg_len = (seg_len + kIdxSpan - 1) & ~(uint64_t)(kIdxSpan - 1);
     seg_len = seg_len < kIdxSegMin ? kIdxSegMin : (seg_len > cap ? cap : seg_len);
