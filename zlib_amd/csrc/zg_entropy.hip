@@ -28,25 +28,96 @@ __device__ __forceinline__ uint32_t parse_step(const uint32_t *__restrict__ matc
     return len ? len : 1u;
 }
 
-__global__ __launch_bounds__(64) void k_parse_spec(uint64_t first, uint64_t end, uint64_t chunk_bytes,
-        const uint32_t *__restrict__ clen, uint32_t c0,
-                                                    uint32_t n_chunks, uint32_t spc,
-                                                    const uint32_t *__restrict__ match, uint64_t base,
-                                                    uint8_t *__restrict__ flag, uint32_t *__restrict__ sub_exit) {
-    const uint64_t gid = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-    const uint32_t ci = (uint32_t)(gid / spc), j = (uint32_t)(gid % spc);
-    if (ci >= n_chunks) return;
-    const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
-    const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
-    const uint64_t s0 = cs + (uint64_t)j * kParseSub;
-    if (s0 >= ce && !(j == 0)) return;
-    const uint64_t s1 = (s0 + kParseSub < ce) ? s0 + kParseSub : ce;
-    uint64_t p = s0;
-    while (p < s1) {
-        flag[p - base] = 1;
-        p += parse_step(match, p - base);
+// k_parse_spec: a workgroup takes kSpecSubs consecutive sub-tiles.  Their match lengths are staged in LDS as one
+// byte each (coalesced reads; 255 stands for "255 or more: look it up"), one lane per sub-tile then walks its
+// chain through LDS, collecting the visited positions in a bit mask, and the workgroup writes the flags out as
+// whole words.  A sub-tile sits kSpecStride bytes from the next so that the walkers spread over the LDS banks.
+constexpr uint32_t kSpecRegion = 65536;                     // positions per workgroup
+constexpr uint32_t kSpecSubs = kSpecRegion / kParseSub;
+constexpr uint32_t kSpecStride = kParseSub + 4;
+constexpr uint32_t kSpecWords = kParseSub / 32 + 1;
+constexpr uint32_t kSpecThreads = 256;
+
+__global__ __launch_bounds__(kSpecThreads) void k_parse_spec(uint64_t first, uint64_t end, uint64_t chunk_bytes,
+                                                              const uint32_t *__restrict__ clen, uint32_t c0,
+                                                              uint32_t n_chunks, uint32_t spc,
+                                                              const uint32_t *__restrict__ match, uint64_t base,
+                                                              uint8_t *__restrict__ flag,
+                                                              uint32_t *__restrict__ sub_exit) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_len[kSpecSubs * kSpecStride];
+    __shared__ uint32_t s_bits[kSpecSubs * kSpecWords];
+    __shared__ uint64_t s_s0[kSpecSubs];  // first position of the sub-tile
+    __shared__ uint32_t s_n[kSpecSubs];   // its positions (0: beyond the chunk's end)
+    const uint32_t tid = threadIdx.x;
+    const uint64_t gid0 = (uint64_t)blockIdx.x * kSpecSubs;
+    if (tid < kSpecSubs) {
+        const uint64_t gid = gid0 + tid;
+        const uint32_t ci = (uint32_t)(gid / spc), j = (uint32_t)(gid % spc);
+        uint64_t s0 = 0;
+        uint32_t n = 0;
+        if (ci < n_chunks) {
+            const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
+            const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
+            s0 = cs + (uint64_t)j * kParseSub;
+            if (s0 < ce) n = ce - s0 < kParseSub ? (uint32_t)(ce - s0) : kParseSub;
+        }
+        s_s0[tid] = s0;
+        s_n[tid] = n;
     }
-    sub_exit[(uint64_t)ci * spc + j] = (uint32_t)(p - cs);
+    for (uint32_t i = tid; i < kSpecSubs * kSpecWords; i += kSpecThreads) s_bits[i] = 0;
+    __syncthreads();
+    for (uint32_t idx = tid * 4; idx < kSpecRegion; idx += kSpecThreads * 4) {
+        const uint32_t sub = idx / kParseSub, off = idx % kParseSub, n = s_n[sub];
+        if (off >= n) continue;
+        const uint32_t *m = match + (s_s0[sub] + off - base);
+        uint32_t pack = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            if (off + i < n) {
+                const uint32_t len = m[i] >> 16;
+                pack |= (len < 255u ? len : 255u) << (8 * i);
+            }
+        }
+        *reinterpret_cast<uint32_t *>(&s_len[sub * kSpecStride + off]) = pack;
+    }
+    __syncthreads();
+    if (tid < kSpecSubs) {
+        const uint64_t gid = gid0 + tid;
+        const uint32_t ci = (uint32_t)(gid / spc), j = (uint32_t)(gid % spc);
+        const uint32_t n = s_n[tid];
+        const uint64_t s0 = s_s0[tid];
+        const uint8_t *len_t = s_len + tid * kSpecStride;
+        uint32_t p = 0, wi = 0, word = 0;
+        while (p < n) {
+            const uint32_t w = p >> 5;
+            if (w != wi) {
+                s_bits[tid * kSpecWords + wi] = word;
+                word = 0;
+                wi = w;
+            }
+            word |= 1u << (p & 31u);
+            uint32_t len = len_t[p];
+            if (len == 255u) len = match[s0 + p - base] >> 16;
+            p += len ? len : 1u;
+        }
+        if (n) s_bits[tid * kSpecWords + wi] = word;
+        if (ci < n_chunks && (n != 0 || j == 0)) {
+            const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
+            sub_exit[gid] = (uint32_t)((n ? s0 : cs) + p - cs);
+        }
+    }
+    __syncthreads();
+    for (uint32_t idx = tid * 4; idx < kSpecRegion; idx += kSpecThreads * 4) {
+        const uint32_t sub = idx / kParseSub, off = idx % kParseSub, n = s_n[sub];
+        if (off >= n) continue;
+        const uint32_t bits = (s_bits[sub * kSpecWords + (off >> 5)] >> (off & 31u)) & 0xFu;
+        uint8_t *f = flag + (s_s0[sub] + off - base);
+        if (off + 4 <= n && (reinterpret_cast<uintptr_t>(f) & 3) == 0) {
+            *reinterpret_cast<uint32_t *>(f) = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
+        } else {
+            for (uint32_t i = 0; i < 4 && off + i < n; i++) f[i] = (uint8_t)((bits >> i) & 1u);
+        }
+    }
 }
 
 __global__ __launch_bounds__(64) void k_parse_fix(uint64_t first, uint64_t end, uint64_t chunk_bytes,
@@ -262,8 +333,8 @@ hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint
     if (e != hipSuccess) return e;
     const uint64_t lanes = (uint64_t)nc * spc;
     const uint32_t blocks = (uint32_t)((lanes + 63) / 64);
-    hipLaunchKernelGGL(k_parse_spec, dim3(blocks), dim3(64), 0, s, g.first, g.end, g.chunk_bytes, g.chunk_len, c0, nc, spc,
-                       match, base, flag, sub_exit);
+    hipLaunchKernelGGL(k_parse_spec, dim3((uint32_t)((lanes + kSpecSubs - 1) / kSpecSubs)), dim3(kSpecThreads), 0, s,
+                       g.first, g.end, g.chunk_bytes, g.chunk_len, c0, nc, spc, match, base, flag, sub_exit);
     hipLaunchKernelGGL(k_parse_fix, dim3(blocks), dim3(64), 0, s, g.first, g.end, g.chunk_bytes, g.chunk_len, c0, nc, spc,
                        match, base, flag, sub_exit, sub_exit2, merged);
     hipLaunchKernelGGL(k_parse_check, dim3(nc), dim3(64), 0, s, g.first, g.end, g.chunk_bytes, g.chunk_len, c0, spc, match,
