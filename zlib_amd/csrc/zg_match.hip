@@ -570,7 +570,9 @@ struct MatchGeom {
 using GeomStream = MatchGeom<kMatchTile, kMaxWindow, kMatchThreads, 1024>;
 using GeomRecord = MatchGeom<kMatchRecordTile, 0, 256, 64>;
 
-// four bytes at an arbitrary LDS byte offset, from two aligned dwords
+// four bytes at an arbitrary LDS byte offset, from two aligned dwords.  gfx950 also reads an LDS dword at any
+// alignment with one ds_read_b32 (tools/probe/probe_lds_unaligned.hip: correct for every offset), but far more
+// slowly: with it k_match took 9.0 ms instead of 4.1 on 64 MiB of text.
 __device__ __forceinline__ uint32_t lds_ld4(const uint8_t *lds, uint32_t off) {
     const uint32_t *w = reinterpret_cast<const uint32_t *>(lds + (off & ~3u));
     const uint32_t lo = w[0], hi = w[1];
