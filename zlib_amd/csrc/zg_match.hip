@@ -741,14 +741,13 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     for (;;) {
 #pragma unroll
         for (int step = 0; step < kHeadSteps; step++) {
-            const bool nearby = (int32_t)so >= so_near;  // may end the search: its first bytes decide
-            const uint32_t off = nearby ? noff : toff;
-            const uint32_t want = nearby ? p0 : pt;
-            const uint32_t msk = nearby ? mask0 : tmask;
-            const uint32_t w = lds_ld4(s_data, so + off);
+            // a candidate within max_len of the position may end the search whatever its length: it is always
+            // measured; one farther away only if it passes the probe
+            const bool nearby = (int32_t)so >= so_near;
+            const uint32_t w = lds_ld4(s_data, so + toff);
             const uint32_t nx = s_next[so];
             const bool guard_end = (int32_t)so >= so_end;  // loop guard: s + min_len < pos
-            const bool survive = ((w ^ want) & msk) == 0;
+            const bool survive = (((w ^ pt) & tmask) == 0) | nearby;
             const bool to_adv = hd & !guard_end & !survive;
             const bool to_fetch = hd & (guard_end | (!survive & (nx == 0)));
             const bool to_eval = hd & !guard_end & survive;
