@@ -1,0 +1,19 @@
+"""A short run of the randomised parity tool (tools/fuzz_parity.py): generated inputs of many shapes, units and
+streams of the HIP path against the oracle.  Longer runs: `python tools/fuzz_parity.py SECONDS SEED`."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_generated_inputs_match_the_oracle():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py")
+    spec = importlib.util.spec_from_file_location("fuzz_parity", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ok, cases = mod.run(15.0, 20261111)
+    assert ok and cases > 100
