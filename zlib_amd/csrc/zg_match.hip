@@ -692,7 +692,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
 
     constexpr int kHeadSteps = ZG_MATCH_STEPS;  // head steps between checks of the deferred work
 #ifndef ZG_EVAL_BATCH
-#define ZG_EVAL_BATCH 4
+#define ZG_EVAL_BATCH 1
 #endif
 #ifndef ZG_FETCH_BATCH
 #define ZG_FETCH_BATCH 2
