@@ -28,7 +28,7 @@ constexpr uint32_t kMatchThreads = 1024;
 constexpr uint32_t kMatchRecordTile = 4096;  // tile of the small geometry used for isolated chunks up to this size
 
 // parse / emit kernel geometry
-constexpr uint32_t kParseSub = 1024;   // positions per speculative parse sub-tile (> kMaxMatch)
+constexpr uint32_t kParseSub = 512;   // positions per speculative parse sub-tile (> kMaxMatch)
 constexpr uint32_t kEmitTile = 4096;   // positions per unit-emission workgroup
 constexpr uint32_t kEmitThreads = 256;
 inline uint32_t parse_subs_per_chunk(uint64_t chunk_bytes) {
