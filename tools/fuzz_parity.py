@@ -70,7 +70,7 @@ def run(budget, seed):
     while time.time() < t_end:
         n = rng.choice([rng.randint(0, 300), rng.randint(300, 20_000), rng.randint(20_000, 150_000)])
         data = gen(n) if n else b""
-        mode = rng.randrange(4)
+        mode = rng.randrange(6)
         if mode == 0:  # units, zlib parameters
             got, want = za.zlib_compressor().compress_packed(data), z.lz77_zlib(data, fast=True)
             what = "lz77 zlib"
@@ -91,6 +91,21 @@ def run(budget, seed):
             want = z.compress_chunked(data, z.DYNAMIC if strat == za.Strategy.Dynamic else z.FIXED, chunk, fast=True)
             what = f"stream chunk={chunk} {strat}"
             assert zlib.decompress(got) == data
+        elif mode == 4:  # streams cut into several batches (scratch arrays restart a window behind each batch)
+            chunk = rng.choice([1024, 4096, 16384, 65536])
+            batch = chunk * rng.randint(1, 4)
+            got = za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk, batch_bytes=batch)
+            want = z.compress_chunked(data, z.DYNAMIC, chunk, fast=True)
+            what = f"stream chunk={chunk} batch={batch}"
+        elif mode == 5:  # a few large records: isolated slots longer than the window
+            recs, pos = [], 0
+            while pos < len(data):
+                m = rng.choice([30_000, 40_000, 70_000, 100_000])
+                recs.append(data[pos:pos + m])
+                pos += m
+            got = b"".join(za.compress_batch(recs, za.Strategy.Dynamic)) if recs else b""
+            want = b"".join(z.compress_chunked(r, z.DYNAMIC, 1 << 20, fast=True) for r in recs)
+            what = f"batch of {len(recs)} large records"
         else:  # record batch
             recs, pos = [], 0
             while pos < len(data):
