@@ -937,7 +937,7 @@ constexpr uint32_t kOpenAgain = 0x80000000u;  // list entry: four-byte chain exh
 //   kPass 1: four-byte chain; the first candidate more than max(5, excl) back that agrees in four bytes is the
 //            answer; entries left without one are marked kOpenAgain.
 //   kPass 2: three-byte chain, marked entries only; the first candidate good for anything decides.
-#ifdef ZG_DEBUG_COUNTERS
+#if defined(ZG_DEBUG_COUNTERS) || defined(ZG_DEBUG_PHASES)
 __device__ unsigned long long g_dbg[64];
 extern "C" int zg_debug_counters(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg));
@@ -947,6 +947,9 @@ extern "C" int zg_debug_counters(unsigned long long *out) {
 // members, one lane busy while the rest of the tile has finished) is parked -- (list index, cursor) in s_park --
 // and finished afterwards by a whole wave: the 64 lanes compare the window from the cursor upward directly
 // with the position's bytes, which finds the same first agreement in a bounded number of passes.
+#ifdef ZG_DEBUG_PHASES
+__device__ long long g_t0[4096];
+#endif
 template <int kPass, uint32_t kParked, uint32_t kThreads>
 __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s_next, uint32_t *s_counter,
                                         uint32_t *s_nparked, uint32_t *s_park, uint32_t *open_t,
@@ -1055,6 +1058,11 @@ __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s
         }
     }
     __syncthreads();
+#ifdef ZG_DEBUG_PHASES
+    if (threadIdx.x == 0) atomicAdd(&g_dbg[kPass == 1 ? 2 : 5], (unsigned long long)(clock64() - *reinterpret_cast<volatile long long *>(&g_t0[blockIdx.x & 4095])));
+    if (threadIdx.x == 0) g_t0[blockIdx.x & 4095] = clock64();
+    __syncthreads();
+#endif
 
     // parked walks, dealt round-robin to the waves
     const uint32_t lane = threadIdx.x & 63;
@@ -1164,8 +1172,20 @@ __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restri
             far_t[i] = (uint32_t)far4_t[idx] | ((uint32_t)far3_t[idx] << 16);
         }
     }
+#ifdef ZG_DEBUG_PHASES
+    if (tid == 0) g_t0[blockIdx.x & 4095] = clock64();
+#endif
     stage_tile(data, next4, base, w0, nbytes, nlinks, s_data, s_next, tid, G::threads, G::data_lds);
     __syncthreads();
+#ifdef ZG_DEBUG_PHASES
+    if (tid == 0) {
+        atomicAdd(&g_dbg[1], (unsigned long long)(clock64() - g_t0[blockIdx.x & 4095]));
+        g_t0[blockIdx.x & 4095] = clock64();
+        atomicAdd(&g_dbg[0], 1ull);
+        atomicAdd(&g_dbg[8], (unsigned long long)n_open);
+    }
+    __syncthreads();
+#endif
 
     const uint32_t pbase = (uint32_t)(t0 - w0);
     const uint64_t tail_room = ce - t0;
@@ -1173,14 +1193,36 @@ __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restri
     lo_pass<1, G::parked, G::threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open, match_t,
                                       pbase, tail_room32, mp.min_len, mp.max_len);
     __syncthreads();  // also orders the list entries written in pass 1 before their readers in pass 2
+#ifdef ZG_DEBUG_PHASES
+    if (tid == 0) {
+        atomicAdd(&g_dbg[3], (unsigned long long)(clock64() - g_t0[blockIdx.x & 4095]));
+        atomicAdd(&g_dbg[9], (unsigned long long)s_nparked);
+        g_t0[blockIdx.x & 4095] = clock64();
+    }
+    __syncthreads();
+#endif
     if (tid == 0) {
         s_counter = 0;
         s_nparked = 0;
     }
     stage_links(next3, base, w0, nlinks, s_next, tid, G::threads);
     __syncthreads();
+#ifdef ZG_DEBUG_PHASES
+    if (tid == 0) {
+        atomicAdd(&g_dbg[4], (unsigned long long)(clock64() - g_t0[blockIdx.x & 4095]));
+        g_t0[blockIdx.x & 4095] = clock64();
+    }
+    __syncthreads();
+#endif
     lo_pass<2, G::parked, G::threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open, match_t,
                                       pbase, tail_room32, mp.min_len, mp.max_len);
+#ifdef ZG_DEBUG_PHASES
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(&g_dbg[6], (unsigned long long)(clock64() - g_t0[blockIdx.x & 4095]));
+        atomicAdd(&g_dbg[10], (unsigned long long)s_nparked);
+    }
+#endif
 }
 
 hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, uint32_t rec_min,
