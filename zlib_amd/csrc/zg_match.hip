@@ -943,6 +943,26 @@ extern "C" int zg_debug_counters(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg));
 }
 #endif
+// The sixteen candidates a .. a + 15 (a a multiple of 16) against the four bytes p0: the lowest j whose candidate
+// agrees in four (kFull) or three bytes, 16 if none.  kEdge also keeps candidates inside [lo, hi).
+template <bool kEdge, bool kFull>
+__device__ __forceinline__ uint32_t scan16(const uint8_t *s_data, uint32_t a, uint32_t p0, uint32_t lo, uint32_t hi) {
+    uint32_t h = 16u;
+    if (kEdge && a >= hi) return h;
+    const uint4 q = *reinterpret_cast<const uint4 *>(s_data + a);
+    const uint32_t w[5] = {q.x, q.y, q.z, q.w, *reinterpret_cast<const uint32_t *>(s_data + a + 16)};
+    const uint32_t want = kFull ? p0 : (p0 & 0x00FFFFFFu);
+#pragma unroll
+    for (int j = 15; j >= 0; j--) {
+        uint32_t v = (j & 3) == 0 ? w[j >> 2] : __builtin_amdgcn_alignbyte(w[(j >> 2) + 1], w[j >> 2], (uint32_t)(j & 3));
+        if (!kFull) v &= 0x00FFFFFFu;
+        bool eq = v == want;
+        if (kEdge) eq = eq && a + (uint32_t)j >= lo && a + (uint32_t)j < hi;
+        h = eq ? (uint32_t)j : h;
+    }
+    return h;
+}
+
 // A walk that has used up its step budget (a rare key sharing its bucket with a frequent one: thousands of
 // members, one lane busy while the rest of the tile has finished) is parked -- (list index, cursor) in s_park --
 // and finished afterwards by a whole wave: the 64 lanes compare the window from the cursor upward directly
@@ -1069,7 +1089,7 @@ __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s
     const uint32_t n_raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_nparked);
     const uint32_t n_parked = n_raw < kParked ? n_raw : kParked;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t want_mask = (kPass == 1 || min_len >= 4u) ? 0xFFFFFFFFu : 0x00FFFFFFu;
+    const bool full = kPass == 1 || min_len >= 4u;  // four bytes have to agree, else three
     for (uint32_t k = wave; k < n_parked; k += kThreads / 64) {
         const uint32_t pi = s_park[k * 2 + 0], s_lo = s_park[k * 2 + 1];
         const uint32_t pe = open_t[pi];
@@ -1079,26 +1099,21 @@ __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s
         if (kPass == 1) pexcl = pexcl > 5u ? pexcl : 5u;
         const uint32_t s_hi = ppo - pexcl;                      // one past the last candidate
         const uint32_t pp0 = lds_ld4(s_data, ppo);
-        uint32_t hit = 0xFFFFFFFFu, hit_x = 0;                  // lowest candidate agreeing in the wanted bytes
-        for (uint32_t b0 = s_lo; b0 < s_hi; b0 += 256) {
-            const uint32_t b = b0 + lane * 4;
-            const uint32_t wa = lds_ld4(s_data, b), wb = lds_ld4(s_data, b + 4);
-            uint32_t h = 0xFFFFFFFFu, hx = 0;
-#pragma unroll
-            for (int j = 3; j >= 0; j--) {
-                const uint32_t v = j == 0 ? wa : __builtin_amdgcn_alignbyte(wb, wa, (uint32_t)j);
-                const uint32_t x = v ^ pp0;
-                if (b + (uint32_t)j < s_hi && (x & want_mask) == 0u) {
-                    h = b + (uint32_t)j;
-                    hx = x;
-                }
-            }
+        uint32_t hit = 0xFFFFFFFFu;                             // lowest candidate agreeing in the wanted bytes
+        // sixteen candidates per lane and round; rounds that touch an end of the range check each candidate
+        const uint32_t a_lo = s_lo & ~15u;
+        for (uint32_t b0 = a_lo; b0 < s_hi; b0 += 1024) {
+            const uint32_t a = b0 + lane * 16;
+            uint32_t j;
+            if (b0 == a_lo || b0 + 1024 > s_hi)
+                j = full ? scan16<true, true>(s_data, a, pp0, s_lo, s_hi) : scan16<true, false>(s_data, a, pp0, s_lo, s_hi);
+            else
+                j = full ? scan16<false, true>(s_data, a, pp0, s_lo, s_hi) : scan16<false, false>(s_data, a, pp0, s_lo, s_hi);
             // lowest hit over the wave: lanes hold ascending, disjoint ranges
-            const uint64_t mh = __ballot(h != 0xFFFFFFFFu);
+            const uint64_t mh = __ballot(j < 16u);
             if (mh) {
                 const int src = __ffsll((unsigned long long)mh) - 1;
-                hit = (uint32_t)__shfl((int)h, src);
-                hit_x = (uint32_t)__shfl((int)hx, src);
+                hit = (uint32_t)__shfl((int)(a + j), src);
                 break;
             }
         }
@@ -1112,6 +1127,7 @@ __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s
                 const uint32_t remain32 = tail_room32 - pidx;
                 const uint32_t cap = remain32 < max_len - 1 ? remain32 : max_len - 1;
                 const uint32_t plim = cap < 4u ? cap : 4u;
+                const uint32_t hit_x = lds_ld4(s_data, hit) ^ pp0;
                 uint32_t m = hit_x ? ((uint32_t)__builtin_ctz(hit_x) >> 3) : 4u;
                 m = m < plim ? m : plim;
                 const uint32_t d = ppo - hit;
