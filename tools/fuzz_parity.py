@@ -67,7 +67,11 @@ def run(budget, seed):
     rng = random.Random(seed)
     t_end = time.time() + budget
     cases = 0
+    t_note = time.time() + 30
     while time.time() < t_end:
+        if time.time() > t_note:  # a line now and then: a silent GPU run is taken to be hung
+            print(f"fuzz: {cases} cases so far", flush=True)
+            t_note = time.time() + 30
         n = rng.choice([rng.randint(0, 300), rng.randint(300, 20_000), rng.randint(20_000, 150_000)])
         data = gen(n) if n else b""
         mode = rng.randrange(6)
