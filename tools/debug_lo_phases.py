@@ -16,3 +16,8 @@ tiles = max(1, v[0])
 names = ["tiles", "stage", "pass1 loop", "pass1 parked", "restage", "pass2 loop", "pass2 parked", "-", "entries", "parked1", "parked2"]
 for k, name in enumerate(names):
     print(f"{name:14s} {v[k]:>16d}  per tile {v[k] / tiles:12.1f}")
+for base, name in ((16, "pass1"), (24, "pass2")):
+    trips, heads, steps, claim, thin = v[base:base + 5]
+    print(f"{name}: trips per wave and tile {trips / tiles / 16:.1f}, walking lanes per trip {heads / max(1, trips):.1f}, "
+          f"cycles per trip in the steps {steps / max(1, trips):.0f}, after them {claim / max(1, trips):.0f}, "
+          f"trips with 1..4 walking lanes {thin / max(1, trips):.2f}")

@@ -984,7 +984,13 @@ __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s
     uint32_t nxt_i = atomicAdd(s_counter, 1u);
     uint32_t nxt_e = nxt_i < n_open ? open_t[nxt_i] : 0u;
     uint32_t nxt_f = nxt_i < n_open ? far_t[nxt_i] : 0u;
+#ifdef ZG_DEBUG_PHASES
+    unsigned long long dbg_trips = 0, dbg_heads = 0, dbg_thin = 0, dbg_steps = 0, dbg_claim = 0;
+#endif
     for (;;) {
+#ifdef ZG_DEBUG_PHASES
+        const long long dbg_ta = clock64();
+#endif
 #pragma unroll
         for (int step = 0; step < kSteps; step++) {
             const uint32_t d = po - so;
@@ -1027,6 +1033,13 @@ __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s
         }
         const uint32_t n_head = (uint32_t)__popcll(__ballot(hd));
         const uint32_t n_fetch = (uint32_t)__popcll(__ballot(ft));
+#ifdef ZG_DEBUG_PHASES
+        dbg_trips += 1;
+        dbg_heads += n_head;
+        if (n_head != 0 && n_head <= 4) dbg_thin += 1;
+        const long long dbg_tb = clock64();
+        dbg_steps += (unsigned long long)(dbg_tb - dbg_ta);
+#endif
         if (n_fetch >= kFetchBatch || (n_fetch != 0 && n_head == 0)) {
             if (ft) {
                 // take the prefetched entry before anything younger is put in flight (see k_match)
@@ -1076,7 +1089,19 @@ __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s
         } else if (n_fetch == 0 && n_head == 0) {
             break;  // no lane has anything left
         }
+#ifdef ZG_DEBUG_PHASES
+        dbg_claim += (unsigned long long)(clock64() - dbg_tb);
+#endif
     }
+#ifdef ZG_DEBUG_PHASES
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_dbg[kPass == 1 ? 16 : 24], dbg_trips);
+        atomicAdd(&g_dbg[kPass == 1 ? 17 : 25], dbg_heads);
+        atomicAdd(&g_dbg[kPass == 1 ? 18 : 26], dbg_steps);
+        atomicAdd(&g_dbg[kPass == 1 ? 19 : 27], dbg_claim);
+        atomicAdd(&g_dbg[kPass == 1 ? 20 : 28], dbg_thin);
+    }
+#endif
     __syncthreads();
 #ifdef ZG_DEBUG_PHASES
     if (threadIdx.x == 0) atomicAdd(&g_dbg[kPass == 1 ? 2 : 5], (unsigned long long)(clock64() - *reinterpret_cast<volatile long long *>(&g_t0[blockIdx.x & 4095])));
