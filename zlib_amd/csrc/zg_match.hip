@@ -561,9 +561,13 @@ uint64_t index_lookback(uint32_t window) { return window; }
 // Geometry of a match workgroup: positions per tile, positions of window staged before them, threads, and how
 // many parked level-2 walks it can hold.  GeomStream is the general one; GeomRecord serves isolated chunks (records) of at most 4 KiB, whose window is
 // the record itself -- a twelfth of the LDS, so that many records are resident per CU.
+#ifndef ZG_LO_STREAM_THREADS
+#define ZG_LO_STREAM_THREADS 1024
+#endif
 template <uint32_t kTileT, uint32_t kWinT, uint32_t kThreadsT, uint32_t kParkedT>
 struct MatchGeom {
     static constexpr uint32_t tile = kTileT, win = kWinT, threads = kThreadsT, parked = kParkedT;
+    static constexpr uint32_t lo_threads = kThreadsT == 1024 ? ZG_LO_STREAM_THREADS : kThreadsT;  // level 2
     static constexpr uint32_t data_lds = kWinT + kTileT + 16 + 272;  // 16: alignment slack, 272: look-ahead + pad
     static constexpr uint32_t next_lds = kWinT + kTileT + 16;
 };
@@ -1163,7 +1167,7 @@ __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s
 }
 
 template <class G>
-__global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restrict__ data, uint64_t first,
+__global__ __launch_bounds__(G::lo_threads) void k_match_lo(const uint8_t *__restrict__ data, uint64_t first,
                                                              uint64_t end, uint64_t chunk_bytes,
                                                              const uint32_t *__restrict__ clen, uint32_t isolated,
                                                              uint32_t c0, uint32_t tiles_per_chunk, MatchParams mp,
@@ -1208,7 +1212,7 @@ __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restri
     // the chain entries of the listed positions, beside the list: far4 | far3 << 16
     {
         const uint16_t *far4_t = far4 + (t0 - base), *far3_t = far3 + (t0 - base);
-        for (uint32_t i = tid; i < n_open; i += G::threads) {
+        for (uint32_t i = tid; i < n_open; i += G::lo_threads) {
             const uint32_t idx = open_t[i] & 0xFFFFu;
             far_t[i] = (uint32_t)far4_t[idx] | ((uint32_t)far3_t[idx] << 16);
         }
@@ -1216,7 +1220,7 @@ __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restri
 #ifdef ZG_DEBUG_PHASES
     if (tid == 0) g_t0[blockIdx.x & 4095] = clock64();
 #endif
-    stage_tile(data, next4, base, w0, nbytes, nlinks, s_data, s_next, tid, G::threads, G::data_lds);
+    stage_tile(data, next4, base, w0, nbytes, nlinks, s_data, s_next, tid, G::lo_threads, G::data_lds);
     __syncthreads();
 #ifdef ZG_DEBUG_PHASES
     if (tid == 0) {
@@ -1231,7 +1235,7 @@ __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restri
     const uint32_t pbase = (uint32_t)(t0 - w0);
     const uint64_t tail_room = ce - t0;
     const uint32_t tail_room32 = tail_room < 0x7FFFFFFFull ? (uint32_t)tail_room : 0x7FFFFFFFu;
-    lo_pass<1, G::parked, G::threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open, match_t,
+    lo_pass<1, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open, match_t,
                                       pbase, tail_room32, mp.min_len, mp.max_len);
     __syncthreads();  // also orders the list entries written in pass 1 before their readers in pass 2
 #ifdef ZG_DEBUG_PHASES
@@ -1246,7 +1250,7 @@ __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restri
         s_counter = 0;
         s_nparked = 0;
     }
-    stage_links(next3, base, w0, nlinks, s_next, tid, G::threads);
+    stage_links(next3, base, w0, nlinks, s_next, tid, G::lo_threads);
     __syncthreads();
 #ifdef ZG_DEBUG_PHASES
     if (tid == 0) {
@@ -1255,7 +1259,7 @@ __global__ __launch_bounds__(G::threads) void k_match_lo(const uint8_t *__restri
     }
     __syncthreads();
 #endif
-    lo_pass<2, G::parked, G::threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open, match_t,
+    lo_pass<2, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open, match_t,
                                       pbase, tail_room32, mp.min_len, mp.max_len);
 #ifdef ZG_DEBUG_PHASES
     __syncthreads();
@@ -1291,11 +1295,11 @@ hipError_t launch_match_lo(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPa
     const uint32_t tpc = match_tiles_per_chunk(g);
     const uint64_t nblocks = (uint64_t)(c1 - c0) * tpc;
     if (match_tile_positions(g) == kMatchRecordTile)
-        hipLaunchKernelGGL(k_match_lo<GeomRecord>, dim3((uint32_t)nblocks), dim3(GeomRecord::threads), 0, s, g.data,
+        hipLaunchKernelGGL(k_match_lo<GeomRecord>, dim3((uint32_t)nblocks), dim3(GeomRecord::lo_threads), 0, s, g.data,
                            g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, far4, next4, far3, next3,
                            base, match, open_list, open_far, open_cnt);
     else
-        hipLaunchKernelGGL(k_match_lo<GeomStream>, dim3((uint32_t)nblocks), dim3(GeomStream::threads), 0, s, g.data,
+        hipLaunchKernelGGL(k_match_lo<GeomStream>, dim3((uint32_t)nblocks), dim3(GeomStream::lo_threads), 0, s, g.data,
                            g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, far4, next4, far3, next3,
                            base, match, open_list, open_far, open_cnt);
     return hipGetLastError();
