@@ -270,6 +270,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict
                                                         uint32_t *__restrict__ freq) {
     __shared__ uint32_t s_hist[kTabStride];
     __shared__ uint32_t s_scan[kEmitThreads];
+    __shared__ uint32_t s_tok[kEmitTile];
     const uint32_t ci = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
     const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
@@ -281,12 +282,21 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict
     const uint32_t b0 = tid * kPer;
     const uint8_t *f = flag + (t0 - base);
     uint32_t fl = 0, cnt = 0;  // flags of my positions as a bit mask
+    if (kPer == 16 && b0 + kPer <= tn && (reinterpret_cast<uintptr_t>(f + b0) & 15) == 0) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(f + b0);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-    for (uint32_t i = 0; i < kPer; i++)
-        if (b0 + i < tn && f[b0 + i]) {
-            fl |= 1u << i;
-            cnt++;
-        }
+        for (uint32_t i = 0; i < 16; i++)
+            if ((w[i >> 2] >> ((i & 3) * 8)) & 0xFFu) fl |= 1u << i;
+        cnt = (uint32_t)__builtin_popcount(fl);
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; i++)
+            if (b0 + i < tn && f[b0 + i]) {
+                fl |= 1u << i;
+                cnt++;
+            }
+    }
     s_scan[tid] = cnt;
     __syncthreads();
     for (uint32_t off = 1; off < kEmitThreads; off <<= 1) {
@@ -295,7 +305,8 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict
         s_scan[tid] += v;
         __syncthreads();
     }
-    uint32_t *tok_out = tokens + (cs - tok_base) + tile_off[(uint64_t)ci * tpc + tile] + (s_scan[tid] - cnt);
+    // the units of the tile are collected in LDS and leave in one coalesced copy
+    uint32_t o = s_scan[tid] - cnt;
     const uint32_t *mt = match + (t0 - base);
     while (fl) {
         const uint32_t i = (uint32_t)__builtin_ctz(fl);
@@ -312,9 +323,12 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict
             tok = data[t0 + r];
             atomicAdd(&s_hist[tok], 1u);
         }
-        *tok_out++ = tok;
+        s_tok[o++] = tok;
     }
     __syncthreads();
+    const uint32_t total = s_scan[kEmitThreads - 1];
+    uint32_t *tok_out = tokens + (cs - tok_base) + tile_off[(uint64_t)ci * tpc + tile];
+    for (uint32_t i = tid; i < total; i += kEmitThreads) tok_out[i] = s_tok[i];
     for (uint32_t i = tid; i < kTabStride; i += kEmitThreads)
         if (s_hist[i]) atomicAdd(&freq[(uint64_t)ci * kTabStride + i], s_hist[i]);
 }
