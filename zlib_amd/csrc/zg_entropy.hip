@@ -341,9 +341,8 @@ hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint
     const uint32_t nc = c1 - c0;
     const uint32_t spc = parse_subs_per_chunk(g.chunk_bytes);
     const uint32_t tpc = emit_tiles_per_chunk(g.chunk_bytes);
-    hipError_t e = hipMemsetAsync(flag, 0, flag_bytes, s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(freq, 0, (size_t)nc * kTabStride * sizeof(uint32_t), s);
+    (void)flag_bytes;  // k_parse_spec writes the flag of every position of every chunk, set or not
+    hipError_t e = hipMemsetAsync(freq, 0, (size_t)nc * kTabStride * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     const uint64_t lanes = (uint64_t)nc * spc;
     const uint32_t blocks = (uint32_t)((lanes + 63) / 64);
