@@ -234,6 +234,17 @@ def test_batching_does_not_change_the_stream(za):
     _same(a, b, "")
 
 
+def test_host_path_above_the_page_touch_threshold(za):
+    """zg_compress on an input large enough for the result pages to be touched ahead: the stream inflates to the
+    input and equals the one made batch by batch with a small batch."""
+    n = (64 << 20) + 12_345
+    data = za.corpus("mixed", n)
+    a = za.compress(data, za.Strategy.Dynamic)
+    assert sysz.decompress(a) == data
+    b = za.compress(data, za.Strategy.Dynamic, batch_bytes=16 << 20)
+    _same(a, b, "")
+
+
 def test_raw_large(za, z):
     data = za.corpus("random", 1_000_003)
     got = za.compress(data, za.Strategy.Raw)
