@@ -549,22 +549,28 @@ int zg_compress(zg_ctx *ctx, const uint8_t *in, size_t n, int strategy, const zg
     // The result buffer is reserved at its bound before the kernels start (untouched pages cost nothing) and a
     // helper thread touches its first pages while the GPU works, so that the download does not pay for the
     // page faults of fresh memory; the buffer is cut to the stream's size at the end.
-    uint8_t *h = static_cast<uint8_t *>(malloc(bound));
-    if (!h) return ZG_ERR_NOMEM;
+    uint8_t *h = static_cast<uint8_t *>(malloc(bound));  // nullptr: the bound is more than the system grants; allocate afterwards
     std::atomic<bool> stop{false};
     std::thread toucher;
-    if (n >= kTouchMin) {
-        toucher = std::thread([h, n, bound, &stop] {
-            const size_t upto = std::min(n, bound);
-            for (size_t off = 0; off < upto && !stop.load(std::memory_order_relaxed); off += 4096)
-                *reinterpret_cast<volatile uint8_t *>(h + off) = 0;
-        });
+    if (h && n >= kTouchMin) {
+        try {
+            toucher = std::thread([h, n, bound, &stop] {
+                const size_t upto = std::min(n, bound);
+                for (size_t off = 0; off < upto && !stop.load(std::memory_order_relaxed); off += 4096)
+                    *reinterpret_cast<volatile uint8_t *>(h + off) = 0;
+            });
+        } catch (...) {  // no thread to be had: the download touches the pages itself
+        }
     }
     size_t got = 0;
     rc = compress_device_locked(c, c->stage_in.as<uint8_t>(), n, strategy, opts, c->stage_out.as<uint8_t>(), bound,
                                 &got, n ? in : nullptr);
     stop.store(true, std::memory_order_relaxed);
     if (toucher.joinable()) toucher.join();
+    if (!rc && !h) {
+        h = static_cast<uint8_t *>(malloc(got ? got : 1));
+        if (!h) return ZG_ERR_NOMEM;
+    }
     hipError_t ce = rc ? hipSuccess : hipMemcpy(h, c->stage_out.p, got, hipMemcpyDeviceToHost);
     if (rc || ce != hipSuccess) {
         free(h);
