@@ -528,10 +528,11 @@ hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint6
     }
     const uint32_t ny = set.n;
     // Segment length.  A wave walks its segment plus `reach` positions on either side, and the LDS table lets
-    // four waves share a CU (which keeps its LDS pipeline about 70 % busy: more waves would not help).  Small
-    // inputs are cut so that one launch fills the machine once; large ones into segments of kIdxSegCap, short
-    // enough for waves on cheap and on costly data (long runs of one byte make every lane of a batch collide)
-    // to even out over several fillings.
+    // four waves share a CU (which keeps its LDS pipeline about 70 % busy: more waves would not help).  The
+    // launch is cut into whole fillings of the machine -- a few waves over would cost a filling of their own:
+    // 256 MiB of 4 KiB records took 5.2 ms with 1026 waves on 1024 places, 3.1 ms with 1023 -- of segments of
+    // about kIdxSegCap, short enough for waves on cheap and on costly data (long runs of one byte make every
+    // lane of a batch collide) to even out over several fillings; longer segments were slower on the mixed corpus.
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
@@ -542,9 +543,13 @@ hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint6
     // leaves the machine no more than two fillings (the tail of the last filling then runs on emptier CUs)
     uint64_t cap = reach <= 4096 ? 8ull * kIdxSegCap : kIdxSegCap;
     if (reach > 4096 && n_pos * ny <= slots * kIdxSegCap) cap = kIdxSegCap / 2;
-    uint64_t seg_len = (n_pos * ny + slots - 1) / slots;
+    // whole fillings: as many as segments of `cap` need, and the segments then as long as those fillings allow
+    // (a twentieth over a whole number of fillings stretches the segments instead of adding a filling)
+    const uint64_t fillings = (n_pos * ny + slots * cap * 19 / 20) / (slots * cap);
+    const uint64_t segs_per_key = slots * (fillings ? fillings : 1) / ny;
+    uint64_t seg_len = (n_pos + segs_per_key - 1) / (segs_per_key ? segs_per_key : 1);
     seg_len = (seg_len + kIdxSpan - 1) & ~(uint64_t)(kIdxSpan - 1);
-    seg_len = seg_len < kIdxSegMin ? kIdxSegMin : (seg_len > cap ? cap : seg_len);
+    seg_len = seg_len < kIdxSegMin ? kIdxSegMin : seg_len;
     const uint64_t nseg = (n_pos + seg_len - 1) / seg_len;
     hipLaunchKernelGGL(k_index_r, dim3((uint32_t)nseg, ny), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, set,
                        base, status, iso_first, iso_bytes, (uint32_t)seg_len);
