@@ -66,19 +66,44 @@ __global__ __launch_bounds__(kSpecThreads) void k_parse_spec(uint64_t first, uin
     }
     for (uint32_t i = tid; i < kSpecSubs * kSpecWords; i += kSpecThreads) s_bits[i] = 0;
     __syncthreads();
-    for (uint32_t idx = tid * 4; idx < kSpecRegion; idx += kSpecThreads * 4) {
-        const uint32_t sub = idx / kParseSub, off = idx % kParseSub, n = s_n[sub];
-        if (off >= n) continue;
-        const uint32_t *m = match + (s_s0[sub] + off - base);
-        uint32_t pack = 0;
+    // four rounds of loads are in flight before the first is used: one round at a time, the loop ran at the
+    // pace of the memory latency
+    constexpr uint32_t kStageUnroll = 4;
+    for (uint32_t idx0 = tid * 4; idx0 < kSpecRegion; idx0 += kSpecThreads * 4 * kStageUnroll) {
+        uint4 q[kStageUnroll];
+        uint32_t fast = 0;
 #pragma unroll
-        for (uint32_t i = 0; i < 4; i++) {
-            if (off + i < n) {
-                const uint32_t len = m[i] >> 16;
-                pack |= (len < 255u ? len : 255u) << (8 * i);
+        for (uint32_t u = 0; u < kStageUnroll; u++) {
+            const uint32_t idx = idx0 + u * kSpecThreads * 4;
+            const uint32_t sub = idx / kParseSub, off = idx % kParseSub, n = s_n[sub];
+            const uint32_t *m = match + (s_s0[sub] + off - base);
+            q[u] = make_uint4(0, 0, 0, 0);
+            if (off + 4 <= n && (reinterpret_cast<uintptr_t>(m) & 15) == 0) {
+                q[u] = *reinterpret_cast<const uint4 *>(m);
+                fast |= 1u << u;
             }
         }
-        *reinterpret_cast<uint32_t *>(&s_len[sub * kSpecStride + off]) = pack;
+#pragma unroll
+        for (uint32_t u = 0; u < kStageUnroll; u++) {
+            const uint32_t idx = idx0 + u * kSpecThreads * 4;
+            const uint32_t sub = idx / kParseSub, off = idx % kParseSub, n = s_n[sub];
+            if (off >= n) continue;
+            uint32_t pack = 0;
+            if (fast & (1u << u)) {
+                const uint32_t l[4] = {q[u].x >> 16, q[u].y >> 16, q[u].z >> 16, q[u].w >> 16};
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) pack |= (l[i] < 255u ? l[i] : 255u) << (8 * i);
+            } else {
+                const uint32_t *m = match + (s_s0[sub] + off - base);
+                for (uint32_t i = 0; i < 4; i++) {
+                    if (off + i < n) {
+                        const uint32_t len = m[i] >> 16;
+                        pack |= (len < 255u ? len : 255u) << (8 * i);
+                    }
+                }
+            }
+            *reinterpret_cast<uint32_t *>(&s_len[sub * kSpecStride + off]) = pack;
+        }
     }
     __syncthreads();
     if (tid < kSpecSubs) {
