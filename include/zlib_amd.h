@@ -147,6 +147,21 @@ uint32_t zg_adler32_combine(uint32_t adler1, uint32_t adler2, uint64_t len2);
 int zg_adler32(zg_ctx *ctx, const uint8_t *in, size_t n, uint32_t *out);
 int zg_adler32_device(zg_ctx *ctx, const void *d_in, size_t n, uint32_t *out);
 
+/* Adler-32 of device memory without any allocation.  No counterpart in the
+ * reference: it is for callers that cannot allocate device memory while they
+ * run (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  The per-segment sums live in a fixed array inside the
+ * library's code object (128 KiB, held by every GPU the library runs on until
+ * the process ends) instead of a buffer of the context, so n is limited to
+ * ZG_ADLER32_NOALLOC_MAX bytes (ZG_ERR_CAPACITY beyond).  ctx must be a context
+ * from zg_init (NULL: ZG_ERR_ARG -- the default context would have to be
+ * created); d_out is a DEVICE pointer to one uint32_t on the ctx's device and
+ * holds the checksum when the call returns (the ctx stream is synchronised).
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU
+ * (two contexts of the same device used from two threads) race. */
+#define ZG_ADLER32_NOALLOC_MAX ((uint64_t)4 << 30)
+int zg_adler32_device_noalloc(zg_ctx *ctx, const void *d_in, size_t n, uint32_t *d_out);
+
 /* ---- LZ77Compressor::compress(&self, &[u8]) -> Vec<LZ77Unit>   (src/lz77.rs:143-207) ----
  * window/min_len/max_len are the public fields of LZ77Compressor
  * (src/lz77.rs:31-38; defaults 144/5/100, zlib 32768/3/258).  Positions

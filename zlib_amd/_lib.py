@@ -20,7 +20,7 @@ SYMBOLS = [
     "zg_init", "zg_destroy", "zg_strerror", "zg_last_error", "zg_free", "zg_compress", "zg_compress_bound",
     "zg_compress_device", "zg_compress_batch", "zg_compress_batch_bound", "zg_compress_batch_device",
     "zg_decompress", "zg_decompress_batch", "zg_decompress_batch_device", "zg_shard_begin", "zg_shard_finish", "zg_adler32_combine", "zg_adler32",
-    "zg_adler32_device", "zg_lz77", "zg_huffman_from_tokens", "zg_profile_enable", "zg_profile_reset",
+    "zg_adler32_device", "zg_adler32_device_noalloc", "zg_lz77", "zg_huffman_from_tokens", "zg_profile_enable", "zg_profile_reset",
     "zg_profile_count", "zg_profile_get", "zg_corpus_fill",
 ]
 
@@ -85,6 +85,7 @@ def _declare(L):
     f("zg_adler32_combine", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64)
     f("zg_adler32", C.c_int, vp, C.c_char_p, sz, C.POINTER(C.c_uint32))
     f("zg_adler32_device", C.c_int, vp, vp, sz, C.POINTER(C.c_uint32))
+    f("zg_adler32_device_noalloc", C.c_int, vp, vp, sz, vp)
     f("zg_lz77", C.c_int, vp, C.c_char_p, sz, sz, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(u32p), C.POINTER(sz))
     f("zg_huffman_from_tokens", C.c_int, vp, u32p, sz, u8p, C.POINTER(C.c_uint16), u8p, C.POINTER(C.c_uint16))
     f("zg_profile_enable", C.c_int, vp, C.c_int)

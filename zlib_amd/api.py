@@ -233,6 +233,19 @@ def adler32(data: bytes, *, ctx: Optional[Context] = None) -> int:
     return out.value
 
 
+def adler32_device(d_in: int, n: int, *, ctx: Optional[Context] = None) -> int:
+    """Adler-32 of n bytes of device memory at d_in."""
+    ctx = ctx or default_context()
+    out = C.c_uint32()
+    _check(_lib.lib().zg_adler32_device(ctx.handle, d_in, n, C.byref(out)), ctx)
+    return out.value
+
+
+def adler32_device_noalloc(d_in: int, n: int, d_out: int, *, ctx: Context) -> None:
+    """zg_adler32_device_noalloc: the checksum goes to the uint32 at DEVICE address d_out; allocates nothing."""
+    _check(_lib.lib().zg_adler32_device_noalloc(ctx.handle, d_in, n, d_out), ctx)
+
+
 @dataclass(frozen=True, order=True)
 class Literal:
     """LZ77Unit::Literal(u8)"""

@@ -58,10 +58,21 @@ struct Scalars {
     uint64_t unused_carry;  // sink for the block-offset scan where only the tile scan is wanted
 };
 
+// Scratch of zg_adler32_device_noalloc: a fixed array in the code object, of which every GPU the library runs
+// on holds its own copy until the process ends.  Words [0, 2 * kNoAllocSegs): the (a, b) of every 256 KiB
+// segment; behind them 3 * 64-bit words per 1024 segments for the first stage of the fold.  Host code never
+// uses the array by name: zg_init asks the runtime for its address on the context's device and keeps that.
+constexpr uint64_t kNoAllocSeg = 256 * 1024;
+constexpr uint64_t kNoAllocMax = ZG_ADLER32_NOALLOC_MAX;
+constexpr uint64_t kNoAllocSegs = kNoAllocMax / kNoAllocSeg;
+constexpr uint64_t kNoAllocWords64 = kNoAllocSegs + 3 * (kNoAllocSegs / 1024 + 1);  // 64-bit words in all
+static __device__ __align__(256) uint64_t g_noalloc_scratch[kNoAllocWords64];
+
 }  // namespace
 
 struct zg_ctx {
     int device = 0;
+    uint64_t *noalloc_scratch = nullptr;  // device address of g_noalloc_scratch on `device`
     hipStream_t stream = nullptr;
     hipStream_t copy = nullptr;  // uploads of host input, overlapped with the kernels on `stream`
     std::mutex mu;
@@ -460,6 +471,13 @@ int zg_init(int device, zg_ctx **ctx) {
     if (!c) return ZG_ERR_NOMEM;
     c->device = device;
     if (const char *e = std::getenv("ZLIB_AMD_SAFE_INDEX")) c->index_safe = e[0] == '1';  // test hook
+    // this device's copy of the fixed scratch array (the current device is `device`)
+    if (hipGetSymbolAddress(reinterpret_cast<void **>(&c->noalloc_scratch), HIP_SYMBOL(g_noalloc_scratch)) !=
+            hipSuccess ||
+        !c->noalloc_scratch) {
+        delete c;
+        return ZG_ERR_NO_DEVICE;
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess) {
         if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -877,6 +895,23 @@ int zg_adler32_device(zg_ctx *ctx, const void *d_in, size_t n, uint32_t *out) {
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->prof) prof_collect(c);
     *out = (h.adler[1] << 16) | h.adler[0];
+    return ZG_OK;
+}
+
+// Allocates nothing: the segment values go to the fixed scratch array of the context's device, the result to
+// caller memory, and no event, buffer or context is created (a NULL ctx would create the default one).
+int zg_adler32_device_noalloc(zg_ctx *c, const void *d_in, size_t n, uint32_t *d_out) {
+    if (!c || !d_out || (!d_in && n)) return ZG_ERR_ARG;
+    if (n > kNoAllocMax) return ZG_ERR_CAPACITY;  // more segments than the fixed scratch holds
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t nseg = (uint32_t)((n + kNoAllocSeg - 1) / kNoAllocSeg);
+    uint32_t *partial = reinterpret_cast<uint32_t *>(c->noalloc_scratch);
+    uint64_t *block_part = c->noalloc_scratch + kNoAllocSegs;
+    // every word the fold reads is written by this call first: nothing of the previous call's contents is used
+    HIPCHK(launch_adler(static_cast<const uint8_t *>(d_in), n, kNoAllocSeg, nseg, nullptr, partial, c->stream));
+    HIPCHK(launch_adler_result(partial, n, kNoAllocSeg, nseg, block_part, d_out, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return ZG_OK;
 }
 

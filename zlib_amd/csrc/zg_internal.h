@@ -145,6 +145,9 @@ hipError_t launch_batch_frame(uint32_t n_chunks, const uint64_t *block_bits, con
 hipError_t launch_adler_fold(const uint32_t *partial, uint64_t n, uint64_t seg_bytes, uint32_t n_seg,
                              uint64_t *block_part /* 3 words per 1024 segments */, uint32_t *state /* [a, b] running */,
                              hipStream_t s);
+// the same fold from the empty stream, the finished checksum (b << 16 | a) stored at `result`
+hipError_t launch_adler_result(const uint32_t *partial, uint64_t n, uint64_t seg_bytes, uint32_t n_seg,
+                               uint64_t *block_part, uint32_t *result, hipStream_t s);
 hipError_t launch_stored(const uint8_t *data, uint64_t n, uint8_t *out, uint32_t *partial, hipStream_t s);
 // inflate: one lane per stream; stream i is in[in_off[i] .. in_off[i+1]), its output slot out[out_off[i] ..
 // out_off[i+1]); size_only counts the output bytes without writing them (and without checking the Adler-32);

@@ -106,8 +106,10 @@ __global__ __launch_bounds__(256) void k_adler_fold1(const uint32_t *__restrict_
     }
 }
 // stage 2: one block joins the block results behind the running state
+// With `result` set the fold starts from the empty stream (1, 0) instead of the running state and leaves the
+// finished checksum b << 16 | a there.
 __global__ __launch_bounds__(256) void k_adler_fold2(const uint64_t *__restrict__ block_part, uint32_t n_blocks,
-                                                      uint32_t *state) {
+                                                      uint32_t *state, uint32_t *result) {
     __shared__ AdlerPart s_part[256];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n_blocks + 255) / 256;
@@ -122,9 +124,13 @@ __global__ __launch_bounds__(256) void k_adler_fold2(const uint64_t *__restrict_
         __syncthreads();
     }
     if (tid == 0) {
-        const AdlerPart run = adler_join(AdlerPart{state[0], state[1], 0}, s_part[0]);
-        state[0] = (uint32_t)run.a;
-        state[1] = (uint32_t)run.b;
+        if (result) {
+            result[0] = ((uint32_t)s_part[0].b << 16) | (uint32_t)s_part[0].a;
+        } else {
+            const AdlerPart run = adler_join(AdlerPart{state[0], state[1], 0}, s_part[0]);
+            state[0] = (uint32_t)run.a;
+            state[1] = (uint32_t)run.b;
+        }
     }
 }
 
@@ -139,7 +145,14 @@ hipError_t launch_adler_fold(const uint32_t *partial, uint64_t n, uint64_t seg_b
     if (!n_seg) return hipSuccess;
     const uint32_t nb = (n_seg + 1023) / 1024;
     hipLaunchKernelGGL(k_adler_fold1, dim3(nb), dim3(256), 0, s, partial, n, seg_bytes, n_seg, block_part);
-    hipLaunchKernelGGL(k_adler_fold2, dim3(1), dim3(256), 0, s, block_part, nb, state);
+    hipLaunchKernelGGL(k_adler_fold2, dim3(1), dim3(256), 0, s, block_part, nb, state, (uint32_t *)nullptr);
+    return hipGetLastError();
+}
+hipError_t launch_adler_result(const uint32_t *partial, uint64_t n, uint64_t seg_bytes, uint32_t n_seg,
+                               uint64_t *block_part, uint32_t *result, hipStream_t s) {
+    const uint32_t nb = (n_seg + 1023) / 1024;  // n_seg == 0: the checksum of the empty stream, 1
+    if (nb) hipLaunchKernelGGL(k_adler_fold1, dim3(nb), dim3(256), 0, s, partial, n, seg_bytes, n_seg, block_part);
+    hipLaunchKernelGGL(k_adler_fold2, dim3(1), dim3(256), 0, s, block_part, nb, (uint32_t *)nullptr, result);
     return hipGetLastError();
 }
 
