@@ -55,7 +55,7 @@ typedef struct zg_ctx zg_ctx;
 
 /* Options; zero-initialise for defaults. */
 typedef struct zg_opts {
-    size_t chunk_bytes; /* input bytes per DEFLATE block; 0 = 1 MiB; multiple of 1024 */
+    size_t chunk_bytes; /* input bytes per DEFLATE block; 0 = 1 MiB; multiple of 1024, <= 256 MiB */
     size_t batch_bytes; /* input bytes processed per pass over the scratch buffers; 0 = 256 MiB */
 } zg_opts;
 
@@ -70,7 +70,12 @@ void zg_free(void *p);
  * Host buffers in and out.  The stream is 78 01, one DEFLATE block per chunk
  * (each matched against the preceding 32 KiB of input), BFINAL on the last,
  * Adler-32 big-endian.  With n <= chunk_bytes it is the reference's stream
- * byte for byte wherever the reference does not panic. */
+ * byte for byte wherever the reference does not panic, with one exception:
+ * ZG_RAW on more than 16 KiB.  The reference writes LEN = data.len() as u16
+ * into every stored block (src/compress.rs:183), which no inflater accepts;
+ * this library writes each block's own length.  Empty input with ZG_RAW
+ * (the reference underflows, src/compress.rs:173) gives one empty final
+ * stored block.  chunk_bytes above 256 MiB: ZG_ERR_UNSUPPORTED. */
 int zg_compress(zg_ctx *ctx, const uint8_t *in, size_t n, int strategy, const zg_opts *opts,
                 uint8_t **out, size_t *out_n);
 
@@ -92,7 +97,8 @@ int zg_compress_batch(zg_ctx *ctx, const uint8_t *in, const size_t *offsets, siz
                       uint8_t **out, size_t **out_offsets);
 
 /* Same on device memory: record i occupies d_len[i] bytes (d_len == NULL: all
- * `stride` bytes) at d_in + i * stride; stride is a multiple of 1024.  d_out
+ * `stride` bytes) at d_in + i * stride; stride is a multiple of 1024, at most
+ * 256 MiB (ZG_ERR_UNSUPPORTED beyond).  d_out
  * needs zg_compress_batch_bound bytes, 4-byte aligned; d_out_offsets receives
  * n_records + 1 byte offsets; *out_bytes the total. */
 size_t zg_compress_batch_bound(size_t stride, size_t n_records, int strategy);

@@ -15,5 +15,5 @@ def test_generated_inputs_match_the_oracle():
     spec = importlib.util.spec_from_file_location("fuzz_parity", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    ok, cases = mod.run(15.0, 20261111)
-    assert ok and cases > 100
+    ok, cases = mod.run(0.0, 20261111, max_cases=400)  # a fixed number of cases: the same ones on every box
+    assert ok and cases == 400

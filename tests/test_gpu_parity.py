@@ -144,8 +144,39 @@ def test_conservative_index_kernel(za, z, monkeypatch):
             got = za.compress(data, za.Strategy.Dynamic, chunk_bytes=65536, ctx=ctx)
             _same(got, za.compress(data, za.Strategy.Dynamic, chunk_bytes=65536), "")
             _same(got, z.compress_chunked(data, z.DYNAMIC, 65536, fast=True), "")
+        # record batches fall back as well (isolated slots: the direct scan that stays inside a slot)
+        recs = [za.corpus("records", 4096, offset=4096 * i) for i in range(40)] + [b"", b"abcabcabcabc" * 50,
+                                                                                   za.corpus("text", 9000, seed=3)]
+        got = za.compress_batch(recs, za.Strategy.Dynamic, ctx=ctx)
+        assert got == za.compress_batch(recs, za.Strategy.Dynamic)
+        for r, g in zip(recs, got):
+            _same(g, z.compress_chunked(r, z.DYNAMIC, 1 << 20, fast=True), f"record of {len(r)} bytes")
     finally:
         ctx.close()
+
+
+def test_limits_are_refused_not_wrapped(za):
+    """Chunks and record slots above 256 MiB would overflow 32-bit bit offsets inside a block: refused."""
+    import ctypes as C
+    import torch
+    from zlib_amd import _lib
+    L = _lib.lib()
+    ctx = za.default_context()
+    d = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    out_n = C.c_size_t()
+    o = _lib.Opts((256 << 20) + 1024, 0)
+    assert L.zg_compress_bound(10, 1, C.byref(o)) == 0
+    assert L.zg_compress_device(ctx.handle, d.data_ptr(), 1024, 1, C.byref(o), d.data_ptr(), 4096,
+                                C.byref(out_n)) == _lib.ERR_UNSUPPORTED
+    assert L.zg_compress_batch_device(ctx.handle, d.data_ptr(), (256 << 20) + 1024, None, 1, 1, d.data_ptr(), 4096,
+                                      d.data_ptr(), C.byref(out_n)) == _lib.ERR_UNSUPPORTED
+    o = _lib.Opts(256 << 20, 0)  # the accepted maximum
+    assert L.zg_compress_bound(10, 1, C.byref(o)) > 0
+    # zg_decompress_batch_device: an output buffer without offsets, streams without input
+    assert L.zg_decompress_batch_device(ctx.handle, d.data_ptr(), d.data_ptr(), 1, d.data_ptr(), None, d.data_ptr(),
+                                        d.data_ptr()) == _lib.ERR_ARG
+    assert L.zg_decompress_batch_device(ctx.handle, None, d.data_ptr(), 1, None, None, d.data_ptr(),
+                                        d.data_ptr()) == _lib.ERR_ARG
 
 
 def test_huffman_tables(za, z):
@@ -335,3 +366,19 @@ def test_record_batch_large_records_and_device_entry(za, z):
         assert sysz.decompress(out[off[i]:off[i + 1]]) == rec
         _same(out[off[i]:off[i + 1]], z.compress_chunked(rec, z.DYNAMIC, 1 << 20, fast=True), i)
     assert sysz.decompress(out[off[n - 1]:off[n]]) == data[(n - 1) * stride:]
+
+
+def test_one_chunk_of_the_accepted_maximum(za):
+    """256 MiB of incompressible bytes as ONE block: more than 2^31 payload bits, the largest the 32-bit tile
+    offsets inside a block have to carry."""
+    n = 256 << 20
+    data = za.corpus("random", n, seed=77)
+    got = za.compress(data, za.Strategy.Dynamic, chunk_bytes=n)
+    assert len(got) > n  # 8-bit codes at best, plus header and trailer
+    d = sysz.decompressobj()
+    pos = 0
+    for at in range(0, len(got), 8 << 20):
+        out = d.decompress(got[at:at + (8 << 20)])
+        assert out == data[pos:pos + len(out)]
+        pos += len(out)
+    assert pos == n and d.eof

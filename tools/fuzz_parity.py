@@ -61,14 +61,15 @@ def first_diff(a, b):
     return next((k for k in range(m) if a[k] != b[k]), m)
 
 
-def run(budget, seed):
-    """Runs cases for `budget` seconds; (all equal, number of cases)."""
+def run(budget, seed, max_cases=None):
+    """Runs cases for `budget` seconds, or exactly `max_cases` cases when that is given (the same cases on every
+    machine); (all equal, number of cases)."""
     global rng
     rng = random.Random(seed)
     t_end = time.time() + budget
     cases = 0
     t_note = time.time() + 30
-    while time.time() < t_end:
+    while (cases < max_cases) if max_cases is not None else (time.time() < t_end):
         if time.time() > t_note:  # a line now and then: a silent GPU run is taken to be hung
             print(f"fuzz: {cases} cases so far", flush=True)
             t_note = time.time() + 30
@@ -128,7 +129,7 @@ def run(budget, seed):
             print(f"MISMATCH case {cases} ({what}, n={len(data)}): lengths {len(got)}/{len(want)}, first difference at {k}; input saved to {path}")
             return False, cases
         cases += 1
-    print(f"fuzz: {cases} cases equal (seed {seed}, {budget:.0f} s)")
+    print(f"fuzz: {cases} cases equal (seed {seed})")
     return True, cases
 
 

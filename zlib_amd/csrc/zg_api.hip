@@ -156,6 +156,10 @@ void prof_collect(zg_ctx *c) {
     c->events.clear();
 }
 
+// Largest chunk / record slot: bit offsets of the encode tiles inside a block are 32-bit (at most 15 bits per
+// input byte) and k_adler sums i * x[i] over one slot in 64 bits.
+constexpr size_t kMaxChunkBytes = (size_t)256 << 20;
+
 struct Plan {
     size_t chunk_bytes;
     size_t batch_chunks;
@@ -163,7 +167,8 @@ struct Plan {
 int make_plan(const zg_opts *opts, Plan *p) {
     size_t cb = (opts && opts->chunk_bytes) ? opts->chunk_bytes : ((size_t)1 << 20);
     size_t bb = (opts && opts->batch_bytes) ? opts->batch_bytes : ((size_t)256 << 20);
-    if (cb < 1024 || (cb % 1024) != 0 || cb > ((size_t)1 << 30)) return ZG_ERR_ARG;
+    if (cb < 1024 || (cb % 1024) != 0) return ZG_ERR_ARG;
+    if (cb > kMaxChunkBytes) return ZG_ERR_UNSUPPORTED;
     size_t bc = bb / cb;
     if (bc < 1) bc = 1;
     if (bc > 32768) bc = 32768;
@@ -585,6 +590,7 @@ int zg_compress(zg_ctx *ctx, const uint8_t *in, size_t n, int strategy, const zg
                                 &got, n ? in : nullptr);
     stop.store(true, std::memory_order_relaxed);
     if (toucher.joinable()) toucher.join();
+    if (rc) (void)hipStreamSynchronize(c->copy);  // an upload may still be reading the caller's buffer
     if (!rc && !h) {
         h = static_cast<uint8_t *>(malloc(got ? got : 1));
         if (!h) return ZG_ERR_NOMEM;
@@ -614,10 +620,11 @@ size_t zg_compress_batch_bound(size_t stride, size_t n_records, int strategy) {
 }
 
 namespace {
-int compress_batch_locked(zg_ctx *c, const uint8_t *d_in, size_t stride, const uint32_t *d_len, size_t n_records,
-                          int strategy, uint8_t *d_out, size_t out_cap, uint64_t *d_off, size_t *out_bytes) {
+int compress_batch_once(zg_ctx *c, const uint8_t *d_in, size_t stride, const uint32_t *d_len, size_t n_records,
+                        int strategy, uint8_t *d_out, size_t out_cap, uint64_t *d_off, size_t *out_bytes) {
     if (strategy != ZG_DYNAMIC && strategy != ZG_FIXED) return ZG_ERR_UNSUPPORTED;
-    if (stride < 1024 || (stride % 1024) != 0 || stride > ((size_t)1 << 30)) return ZG_ERR_ARG;
+    if (stride < 1024 || (stride % 1024) != 0) return ZG_ERR_ARG;
+    if (stride > kMaxChunkBytes) return ZG_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(d_out) & 3) != 0) return ZG_ERR_ARG;
     if (n_records > 0xFFFFFFFFull) return ZG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
@@ -674,10 +681,20 @@ int compress_batch_locked(zg_ctx *c, const uint8_t *d_in, size_t stride, const u
     HIPCHK(hipMemcpyAsync(&h, c->scalars.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->prof) prof_collect(c);
-    if (h.status & 2u) return ZG_ERR_INTERNAL;  // the exchange-order check of the index kernel tripped
+    if (h.status & 2u) return kRetrySafe;  // the exchange-order check of the index kernel tripped
     if (h.status & 1u) return ZG_ERR_CAPACITY;
     *out_bytes = (size_t)h.carry;
     return ZG_OK;
+}
+
+int compress_batch_locked(zg_ctx *c, const uint8_t *d_in, size_t stride, const uint32_t *d_len, size_t n_records,
+                          int strategy, uint8_t *d_out, size_t out_cap, uint64_t *d_off, size_t *out_bytes) {
+    int rc = compress_batch_once(c, d_in, stride, d_len, n_records, strategy, d_out, out_cap, d_off, out_bytes);
+    if (rc == kRetrySafe && !c->index_safe) {  // once more with the index kernel that relies on no LDS ordering
+        c->index_safe = true;
+        rc = compress_batch_once(c, d_in, stride, d_len, n_records, strategy, d_out, out_cap, d_off, out_bytes);
+    }
+    return rc == kRetrySafe ? ZG_ERR_INTERNAL : rc;
 }
 }  // namespace
 
@@ -738,9 +755,14 @@ int zg_compress_batch(zg_ctx *ctx, const uint8_t *in, const size_t *offsets, siz
         free(ho);
         return ZG_ERR_NOMEM;
     }
-    if (got) HIPCHK(hipMemcpy(h, c->stage_out.p, got, hipMemcpyDeviceToHost));
-    if (n_records)
-        HIPCHK(hipMemcpy(off64.data(), c->rec_off.p, (n_records + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    hipError_t ce = got ? hipMemcpy(h, c->stage_out.p, got, hipMemcpyDeviceToHost) : hipSuccess;
+    if (ce == hipSuccess && n_records)
+        ce = hipMemcpy(off64.data(), c->rec_off.p, (n_records + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    if (ce != hipSuccess) {
+        free(h);
+        free(ho);
+        HIPCHK(ce);
+    }
     for (size_t i = 0; i <= n_records; i++) ho[i] = (size_t)off64[i];
     *out = h;
     *out_offsets = ho;
@@ -787,6 +809,7 @@ int zg_decompress_batch_device(zg_ctx *ctx, const void *d_in, const uint64_t *d_
     zg_ctx *c = resolve(ctx, &rc);
     if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
     if (!d_in_offsets || !d_out_len || !d_status || n_streams > 0xFFFFFFFFull) return ZG_ERR_ARG;
+    if ((d_out && !d_out_offsets) || (!d_in && n_streams)) return ZG_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
     // d_out == NULL: sizes only (no output is written, the Adler-32 is not checked)
@@ -853,7 +876,14 @@ int zg_decompress_batch(zg_ctx *ctx, const uint8_t *in, const size_t *offsets, s
         free(ho);
         return ZG_ERR_NOMEM;
     }
-    if (total_out) HIPCHK(hipMemcpy(h, c->stage_out.p, total_out, hipMemcpyDeviceToHost));
+    if (total_out) {
+        const hipError_t ce = hipMemcpy(h, c->stage_out.p, total_out, hipMemcpyDeviceToHost);
+        if (ce != hipSuccess) {
+            free(h);
+            free(ho);
+            HIPCHK(ce);
+        }
+    }
     for (size_t i = 0; i <= n_streams; i++) ho[i] = (size_t)ooff[i];
     *out = h;
     *out_offsets = ho;
@@ -879,14 +909,10 @@ uint32_t zg_adler32_combine(uint32_t adler1, uint32_t adler2, uint64_t len2) {
     return (uint32_t)(b << 16 | a);
 }
 
-int zg_adler32_device(zg_ctx *ctx, const void *d_in, size_t n, uint32_t *out) {
-    int rc = 0;
-    zg_ctx *c = resolve(ctx, &rc);
-    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
-    if (!out || (!d_in && n)) return ZG_ERR_ARG;
-    std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(hipSetDevice(c->device));
-    rc = init_scalars(c, 0);
+namespace {
+// the caller holds c->mu
+int adler32_device_locked(zg_ctx *c, const void *d_in, size_t n, uint32_t *out) {
+    int rc = init_scalars(c, 0);
     if (rc) return rc;
     rc = run_adler(c, static_cast<const uint8_t *>(d_in), n);
     if (rc) return rc;
@@ -896,6 +922,17 @@ int zg_adler32_device(zg_ctx *ctx, const void *d_in, size_t n, uint32_t *out) {
     if (c->prof) prof_collect(c);
     *out = (h.adler[1] << 16) | h.adler[0];
     return ZG_OK;
+}
+}  // namespace
+
+int zg_adler32_device(zg_ctx *ctx, const void *d_in, size_t n, uint32_t *out) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (!out || (!d_in && n)) return ZG_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    return adler32_device_locked(c, d_in, n, out);
 }
 
 // Allocates nothing: the segment values go to the fixed scratch array of the context's device, the result to
@@ -920,13 +957,11 @@ int zg_adler32(zg_ctx *ctx, const uint8_t *in, size_t n, uint32_t *out) {
     zg_ctx *c = resolve(ctx, &rc);
     if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
     if (!out || (!in && n)) return ZG_ERR_ARG;
-    {
-        std::lock_guard<std::mutex> lk(c->mu);
-        HIPCHK(hipSetDevice(c->device));
-        HIPCHK(c->stage_in.ensure(n + 64));
-        if (n) HIPCHK(hipMemcpyAsync(c->stage_in.p, in, n, hipMemcpyHostToDevice, c->stream));
-    }
-    return zg_adler32_device(c, c->stage_in.p, n, out);
+    std::lock_guard<std::mutex> lk(c->mu);  // one lock over upload and kernels: stage_in stays this call's
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(c->stage_in.ensure(n + 64));
+    if (n) HIPCHK(hipMemcpyAsync(c->stage_in.p, in, n, hipMemcpyHostToDevice, c->stream));
+    return adler32_device_locked(c, c->stage_in.p, n, out);
 }
 
 int zg_lz77(zg_ctx *ctx, const uint8_t *in, size_t n, size_t start, uint32_t window, uint32_t min_len,
@@ -936,6 +971,7 @@ int zg_lz77(zg_ctx *ctx, const uint8_t *in, size_t n, size_t start, uint32_t win
     if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
     if (!tokens || !n_tokens || (!in && n) || start > n) return ZG_ERR_ARG;
     if (min_len < 3 || max_len > kMaxMatch) return ZG_ERR_UNSUPPORTED;
+    if (n - start > kMaxChunkBytes) return ZG_ERR_UNSUPPORTED;  // the call is one chunk
     if (window > kMaxWindow) window = kMaxWindow;  // with_window_size / set_window_size clamp, src/lz77.rs:90-120
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
@@ -964,7 +1000,13 @@ int zg_lz77(zg_ctx *ctx, const uint8_t *in, size_t n, size_t start, uint32_t win
     }
     uint32_t *h = static_cast<uint32_t *>(malloc((nt ? nt : 1) * sizeof(uint32_t)));
     if (!h) return ZG_ERR_NOMEM;
-    if (nt) HIPCHK(hipMemcpy(h, c->tokens.p, (size_t)nt * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (nt) {
+        const hipError_t ce = hipMemcpy(h, c->tokens.p, (size_t)nt * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (ce != hipSuccess) {
+            free(h);
+            HIPCHK(ce);
+        }
+    }
     if (c->prof) prof_collect(c);
     *tokens = h;
     *n_tokens = nt;

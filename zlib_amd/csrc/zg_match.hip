@@ -510,8 +510,9 @@ hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint6
                         uint32_t window, const IndexSet &set, uint64_t base, uint32_t *status, bool safe,
                         uint64_t iso_first, uint32_t iso_bytes, hipStream_t s) {
     if (r1 <= r0 || set.n == 0) return hipSuccess;
-    const bool brute = window < 2048 || n_view < 64;
-    if (brute || (safe && !iso_bytes)) {  // the conservative variant has no notion of isolated slots
+    // the conservative k_index has no notion of isolated slots: those fall back to the direct scan, which has
+    const bool brute = window < 2048 || n_view < 64 || (safe && iso_bytes);
+    if (brute || safe) {
         for (uint32_t which = 0; which < set.n; which++) {
             const int key = set.key[which];
             uint16_t *far = set.far[which], *next = set.next[which];
