@@ -155,6 +155,37 @@ def test_conservative_index_kernel(za, z, monkeypatch):
         ctx.close()
 
 
+def test_search_along_the_parse(za, z, monkeypatch):
+    """The optional search that visits only the positions the greedy parse can reach (k_walk; four-byte chains
+    in LDS, three-byte chains beside them) gives the streams and units of the full search."""
+    monkeypatch.setenv("ZLIB_AMD_WALK", "1")
+    ctx = za.Context(0)
+    try:
+        rng = random.Random(77)
+        cases = [(za.corpus("text", 3 << 20, seed=11), 1 << 20), (za.corpus("mixed", (4 << 20) + 777, seed=12), 1 << 20),
+                 (za.corpus("binary", 1 << 20, seed=13), 1 << 18), (za.corpus("random", 300_000, seed=14), 65536),
+                 (b"a" * 200_000, 65536), (b"abcdefgh" * 30_000, 1 << 20), (bytes(300_000), 1 << 17),
+                 (bytes(rng.choice(b"ab") for _ in range(150_000)), 32768),
+                 (b"".join(bytes([rng.randrange(4)]) * rng.randint(1, 600) for _ in range(2000)), 65536),
+                 (za.corpus("text", 40_000, seed=15), 1 << 20), (b"", 1024), (b"abc", 1024)]
+        for data, chunk in cases:
+            got = za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk, ctx=ctx)
+            _same(got, za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk), f"{len(data)} bytes, chunk {chunk}")
+        # units with other parameters: windows and minimum lengths (4: no three-byte chains; 5 and more)
+        data = za.corpus("text", 90_000, seed=16) + bytes(rng.choice(b"xyz") for _ in range(30_000))
+        for window, mn, mx in ((32768, 3, 258), (32768, 4, 258), (8192, 5, 100), (4096, 3, 32), (2048, 6, 258)):
+            comp = za.LZ77Compressor.with_window_size(window)
+            comp.min_match_length, comp.max_match_length = mn, mx
+            _same(comp.compress_packed(data[:20_000], ctx=ctx), z.lz77_compress(data[:20_000], 0, window, mn, mx),
+                  f"w={window} min={mn} max={mx}")
+            _same(comp.compress_packed(data, ctx=ctx), comp.compress_packed(data), f"w={window} min={mn} max={mx} long")
+        # a batch of large records (isolated slots with the general tile geometry)
+        recs = [za.corpus("text", 70_000, seed=1), za.corpus("binary", 50_000, seed=2), b"", za.corpus("mixed", 33_000, seed=4)]
+        assert za.compress_batch(recs, ctx=ctx) == za.compress_batch(recs)
+    finally:
+        ctx.close()
+
+
 def test_limits_are_refused_not_wrapped(za):
     """Chunks and record slots above 256 MiB would overflow 32-bit bit offsets inside a block: refused."""
     import ctypes as C

@@ -44,8 +44,8 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
-enum KernelId { K_INDEX, K_MATCH, K_MATCH_LO, K_PARSE, K_HUFFMAN, K_TILEBITS, K_OFFSETS, K_ENCODE, K_ADLER, K_STORED, K_INFLATE, K_MISC, K_COUNT };
-const char *const kKernelNames[K_COUNT] = {"k_index", "k_match", "k_match_lo", "k_parse", "k_huffman", "k_tile_bits",
+enum KernelId { K_INDEX, K_WALK, K_MATCH, K_MATCH_LO, K_PARSE, K_HUFFMAN, K_TILEBITS, K_OFFSETS, K_ENCODE, K_ADLER, K_STORED, K_INFLATE, K_MISC, K_COUNT };
+const char *const kKernelNames[K_COUNT] = {"k_index", "k_walk", "k_match", "k_match_lo", "k_parse", "k_huffman", "k_tile_bits",
                                            "k_offsets", "k_encode", "k_adler", "k_stored", "k_inflate", "misc"};
 
 // device scalars
@@ -53,7 +53,8 @@ struct Scalars {
     uint64_t carry;       // absolute bit offset of the next block
     uint64_t out_bytes;   // final size written by k_trailer
     uint32_t adler[2];    // running a, b
-    uint32_t status;      // bit 0: output capacity exceeded, bit 1: index exchange out of order
+    uint32_t status;      // bit 0: output capacity exceeded, bit 1: index exchange out of order, bit 2: the parse
+                          // stood on a position the walk kernel had not searched
     uint32_t pad;
     uint64_t unused_carry;  // sink for the block-offset scan where only the tile scan is wanted
 };
@@ -77,13 +78,18 @@ struct zg_ctx {
     hipStream_t copy = nullptr;  // uploads of host input, overlapped with the kernels on `stream`
     std::mutex mu;
     std::string err;
-    DevBuf shard_buf, far, next, far4, next4, far3, next3, open_list, open_far, open_cnt, rec_len, rec_off, inf_off, inf_len, inf_status, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
+    DevBuf walk_exit, shard_buf, far, next, far4, next4, far3, next3, open_list, open_far, open_cnt, rec_len, rec_off, inf_off, inf_len, inf_status, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
         scalars, stage_in, stage_out, misc, flag, sub_exit, sub_exit2, merged, tile_cnt, adler_blk;
     // shard state kept between zg_shard_begin and zg_shard_finish
     bool shard_active = false;
     uint64_t shard_total_bits = 0;
     // set once the exchange-based index kernel has reported an out-of-order exchange: use k_index from then on
     bool index_safe = false;
+    // The search along the parse only (k_walk) is chosen per context (ZLIB_AMD_WALK=1); the default searches every
+    // position (k_match, k_match_lo), which is faster on text-like and incompressible input.  walk_off also is
+    // set should the parse ever stand on an unsearched position (never seen; the check is cheap).
+    bool walk_off = true;
+    int cus = 256;
     // profiling
     bool prof = false;
     struct Ev {
@@ -232,15 +238,25 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
     const uint64_t ib0 = (bs > back ? bs - back : 0) & ~(uint64_t)15;  // scratch arrays start here
     const uint64_t ix0 = g.isolated ? bs : ib0;                        // first indexed position
     const uint64_t span = be - ib0;
-    const bool two_level = mp.min_len < 5;  // lengths 3 and 4 need the three-byte chains
     const uint64_t iso_first = g.isolated ? g.first : 0;
     const uint32_t iso_bytes = g.isolated ? (uint32_t)g.chunk_bytes : 0u;
+    // Two ways to the match of every position the parse stands on.  The walk (k_walk): the search runs along the
+    // parse only, on the four-byte chains, with the three-byte chains beside it for lengths of three.  The full
+    // search (k_match, k_match_lo): every position, five-byte chains first, then four- and three-byte chains for
+    // the positions left open; it serves small records and stands in should the walk's check ever fail.
+    const bool walk = !c->walk_off && match_tile_positions(g) == kMatchTile;
+    const bool two_level = mp.min_len < 5;  // full search: lengths 3 and 4 need the shorter chains
+    const bool need5 = !walk, need4 = walk || two_level, need3 = walk ? mp.min_len < 4 : two_level;
     const uint32_t rec_min = mp.min_len < 5 ? 5u : mp.min_len;
-    HIPCHK(c->far.ensure(span * 2 + 64));
-    HIPCHK(c->next.ensure(span * 2 + 64));
-    if (two_level) {
+    if (need5) {
+        HIPCHK(c->far.ensure(span * 2 + 64));
+        HIPCHK(c->next.ensure(span * 2 + 64));
+    }
+    if (need4) {
         HIPCHK(c->far4.ensure(span * 2 + 64));
         HIPCHK(c->next4.ensure(span * 2 + 64));
+    }
+    if (need3) {
         HIPCHK(c->far3.ensure(span * 2 + 64));
         HIPCHK(c->next3.ensure(span * 2 + 64));
     }
@@ -249,18 +265,26 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
     if (span) {
         uint32_t *status = &c->scalars.as<Scalars>()->status;
         IndexSet set;
-        set.add(5, c->far.as<uint16_t>(), c->next.as<uint16_t>());
-        if (two_level) {
+        if (need5) set.add(5, c->far.as<uint16_t>(), c->next.as<uint16_t>());
+        if (need4) set.add(4, c->far4.as<uint16_t>(), c->next4.as<uint16_t>());
+        if (need3) set.add(3, c->far3.as<uint16_t>(), c->next3.as<uint16_t>());
+        if (two_level && !walk) {
             const uint64_t ntiles = (uint64_t)(c1 - c0) * match_tiles_per_chunk(g);
             HIPCHK(c->open_list.ensure(ntiles * match_tile_positions(g) * sizeof(uint32_t)));
             HIPCHK(c->open_far.ensure(ntiles * match_tile_positions(g) * sizeof(uint32_t)));
             HIPCHK(c->open_cnt.ensure(ntiles * sizeof(uint32_t)));
-            set.add(4, c->far4.as<uint16_t>(), c->next4.as<uint16_t>());
-            set.add(3, c->far3.as<uint16_t>(), c->next3.as<uint16_t>());
         }
         LAUNCH(K_INDEX, launch_index(g.data, g.end, ix0, be, bs, mp.window, set, ib0, status, c->index_safe, iso_first,
                                      iso_bytes, c->stream));
-        if (two_level) {
+        if (walk) {
+            const uint32_t tpr = walk_tiles_per_run(g, c1 - c0, (uint32_t)c->cus);
+            const uint64_t runs = (uint64_t)(c1 - c0) * ((match_tiles_per_chunk(g) + tpr - 1) / tpr);
+            HIPCHK(c->walk_exit.ensure(runs * kWalkExitWords * sizeof(uint32_t)));
+            const uint16_t *f3 = need3 ? c->far3.as<uint16_t>() : c->far4.as<uint16_t>();  // unread without need3
+            const uint16_t *n3 = need3 ? c->next3.as<uint16_t>() : c->next4.as<uint16_t>();
+            LAUNCH(K_WALK, launch_walk(g, c0, c1, mp, c->far4.as<uint16_t>(), c->next4.as<uint16_t>(), f3, n3, ib0,
+                                       c->match.as<uint32_t>(), c->walk_exit.as<uint32_t>(), tpr, c->stream));
+        } else if (two_level) {
             LAUNCH(K_MATCH, launch_match(g, c0, c1, mp, rec_min, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
                                          c->match.as<uint32_t>(), c->open_list.as<uint32_t>(),
                                          c->open_cnt.as<uint32_t>(), c->stream));
@@ -284,7 +308,7 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
         LAUNCH(K_PARSE, launch_parse(g, c0, c1, c->match.as<uint32_t>(), ib0, c->flag.as<uint8_t>(), span,
                                      c->sub_exit.as<uint32_t>(), c->sub_exit2.as<uint32_t>(), c->merged.as<uint8_t>(),
                                      c->tile_cnt.as<uint32_t>(), c->tokens.as<uint32_t>(), bs, c->ntok.as<uint32_t>(),
-                                     c->freq.as<uint32_t>(), c->stream));
+                                     c->freq.as<uint32_t>(), &c->scalars.as<Scalars>()->status, c->stream));
     }
     if (want_codes)
         LAUNCH(K_HUFFMAN, launch_huffman(c1 - c0, strategy, c->freq.as<uint32_t>(), final_chunk, c->tab.as<uint32_t>(),
@@ -341,7 +365,8 @@ size_t stored_size(size_t n) {
 }
 
 constexpr size_t kTouchMin = (size_t)64 << 20;  // zg_compress: inputs from this size on get their result pages touched ahead
-constexpr int kRetrySafe = 1;  // internal: the index kernel asked for the conservative variant
+constexpr int kRetrySafe = 1;    // internal: the index kernel asked for the conservative variant
+constexpr int kRetryNoWalk = 2;  // internal: the parse left the positions the walk kernel had searched
 
 // h_in != nullptr: the input is still in host memory; it is copied to d_in batch by batch on
 // the context's copy stream, each batch's kernels waiting only for their own bytes, so that the upload of
@@ -435,6 +460,7 @@ int compress_device_once(zg_ctx *c, const uint8_t *d_in, size_t n, int strategy,
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->prof) prof_collect(c);
     if (h.status & 2u) return kRetrySafe;
+    if (h.status & 4u) return kRetryNoWalk;
     if (h.status & 1u) return ZG_ERR_CAPACITY;
     *out_n = (size_t)h.out_bytes;
     return ZG_OK;
@@ -443,11 +469,13 @@ int compress_device_once(zg_ctx *c, const uint8_t *d_in, size_t n, int strategy,
 int compress_device_locked(zg_ctx *c, const uint8_t *d_in, size_t n, int strategy, const zg_opts *opts,
                            uint8_t *d_out, size_t out_cap, size_t *out_n, const uint8_t *h_in = nullptr) {
     int rc = compress_device_once(c, d_in, n, strategy, opts, d_out, out_cap, out_n, h_in);
-    if (rc == kRetrySafe) {
-        c->index_safe = true;
+    for (int attempt = 0; attempt < 2 && (rc == kRetrySafe || rc == kRetryNoWalk); attempt++) {
+        if (rc == kRetrySafe && c->index_safe) break;
+        if (rc == kRetryNoWalk && c->walk_off) break;
+        (rc == kRetrySafe ? c->index_safe : c->walk_off) = true;
         rc = compress_device_once(c, d_in, n, strategy, opts, d_out, out_cap, out_n);  // the input is on the device by now
     }
-    return rc;
+    return (rc == kRetrySafe || rc == kRetryNoWalk) ? ZG_ERR_INTERNAL : rc;
 }
 
 zg_ctx *resolve(zg_ctx *ctx, int *rc) {
@@ -476,6 +504,9 @@ int zg_init(int device, zg_ctx **ctx) {
     if (!c) return ZG_ERR_NOMEM;
     c->device = device;
     if (const char *e = std::getenv("ZLIB_AMD_SAFE_INDEX")) c->index_safe = e[0] == '1';  // test hook
+    if (const char *e = std::getenv("ZLIB_AMD_WALK")) c->walk_off = e[0] != '1';
+    if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->cus <= 0)
+        c->cus = 256;
     // this device's copy of the fixed scratch array (the current device is `device`)
     if (hipGetSymbolAddress(reinterpret_cast<void **>(&c->noalloc_scratch), HIP_SYMBOL(g_noalloc_scratch)) !=
             hipSuccess ||
@@ -498,7 +529,7 @@ void zg_destroy(zg_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf *bufs[] = {&c->shard_buf, &c->far, &c->next, &c->far4, &c->next4, &c->far3, &c->next3, &c->open_list, &c->open_far, &c->open_cnt, &c->rec_len, &c->rec_off, &c->inf_off, &c->inf_len, &c->inf_status, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
+    DevBuf *bufs[] = {&c->walk_exit, &c->shard_buf, &c->far, &c->next, &c->far4, &c->next4, &c->far3, &c->next3, &c->open_list, &c->open_far, &c->open_cnt, &c->rec_len, &c->rec_off, &c->inf_off, &c->inf_len, &c->inf_status, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
                       &c->block_bits, &c->bit_off, &c->tile_bits, &c->adler_part, &c->scalars, &c->stage_in,
                       &c->stage_out, &c->misc, &c->flag, &c->sub_exit, &c->sub_exit2, &c->merged, &c->tile_cnt,
                       &c->adler_blk};
@@ -682,6 +713,7 @@ int compress_batch_once(zg_ctx *c, const uint8_t *d_in, size_t stride, const uin
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->prof) prof_collect(c);
     if (h.status & 2u) return kRetrySafe;  // the exchange-order check of the index kernel tripped
+    if (h.status & 4u) return kRetryNoWalk;
     if (h.status & 1u) return ZG_ERR_CAPACITY;
     *out_bytes = (size_t)h.carry;
     return ZG_OK;
@@ -690,11 +722,14 @@ int compress_batch_once(zg_ctx *c, const uint8_t *d_in, size_t stride, const uin
 int compress_batch_locked(zg_ctx *c, const uint8_t *d_in, size_t stride, const uint32_t *d_len, size_t n_records,
                           int strategy, uint8_t *d_out, size_t out_cap, uint64_t *d_off, size_t *out_bytes) {
     int rc = compress_batch_once(c, d_in, stride, d_len, n_records, strategy, d_out, out_cap, d_off, out_bytes);
-    if (rc == kRetrySafe && !c->index_safe) {  // once more with the index kernel that relies on no LDS ordering
-        c->index_safe = true;
+    for (int attempt = 0; attempt < 2 && (rc == kRetrySafe || rc == kRetryNoWalk); attempt++) {
+        // once more with the index kernel that relies on no LDS ordering / with every position searched
+        if (rc == kRetrySafe && c->index_safe) break;
+        if (rc == kRetryNoWalk && c->walk_off) break;
+        (rc == kRetrySafe ? c->index_safe : c->walk_off) = true;
         rc = compress_batch_once(c, d_in, stride, d_len, n_records, strategy, d_out, out_cap, d_off, out_bytes);
     }
-    return rc == kRetrySafe ? ZG_ERR_INTERNAL : rc;
+    return (rc == kRetrySafe || rc == kRetryNoWalk) ? ZG_ERR_INTERNAL : rc;
 }
 }  // namespace
 
@@ -986,7 +1021,7 @@ int zg_lz77(zg_ctx *ctx, const uint8_t *in, size_t n, size_t start, uint32_t win
     rc = ensure_chunk_meta(c, 1, 1);
     if (rc) return rc;
     uint32_t nt = 0;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = 0;; attempt++) {
         rc = init_scalars(c, 0);
         if (rc) return rc;
         rc = run_front(c, g, 0, 1, MatchParams{window, min_len, max_len}, ZG_DYNAMIC, -1, false);
@@ -995,8 +1030,11 @@ int zg_lz77(zg_ctx *ctx, const uint8_t *in, size_t n, size_t start, uint32_t win
         HIPCHK(hipMemcpyAsync(&nt, c->ntok.p, sizeof nt, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(&hs, c->scalars.p, sizeof hs, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (!(hs.status & 2u)) break;
-        c->index_safe = true;
+        if (!(hs.status & 6u)) break;
+        if (attempt >= 2 || ((hs.status & 2u) && c->index_safe) || ((hs.status & 4u) && c->walk_off))
+            return ZG_ERR_INTERNAL;
+        if (hs.status & 2u) c->index_safe = true;
+        if (hs.status & 4u) c->walk_off = true;
     }
     uint32_t *h = static_cast<uint32_t *>(malloc((nt ? nt : 1) * sizeof(uint32_t)));
     if (!h) return ZG_ERR_NOMEM;
@@ -1098,10 +1136,15 @@ int zg_shard_begin(zg_ctx *ctx, const void *d_in, size_t halo, size_t n, int str
         Scalars h;
         HIPCHK(hipMemcpyAsync(&h, c->scalars.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if ((h.status & 2u) && !c->index_safe && attempt == 0) {  // redo with the conservative index kernel
+        if ((h.status & 2u) && !c->index_safe && attempt < 2) {  // redo with the conservative index kernel
             c->index_safe = true;
             continue;
         }
+        if ((h.status & 4u) && !c->walk_off && attempt < 2) {  // redo with every position searched
+            c->walk_off = true;
+            continue;
+        }
+        if (h.status & 6u) return ZG_ERR_INTERNAL;
         if (h.status & 1u) return ZG_ERR_CAPACITY;
         info->total_bits = h.carry;
         info->adler = (h.adler[1] << 16) | h.adler[0];

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict
                                                         const uint32_t *__restrict__ match, uint64_t base,
                                                         const uint32_t *__restrict__ tile_off,
                                                         uint32_t *__restrict__ tokens, uint64_t tok_base,
-                                                        uint32_t *__restrict__ freq) {
+                                                        uint32_t *__restrict__ freq, uint32_t *__restrict__ status) {
     __shared__ uint32_t s_hist[kTabStride];
     __shared__ uint32_t s_scan[kEmitThreads];
     __shared__ uint32_t s_tok[kEmitTile];
@@ -337,7 +337,11 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict
         const uint32_t i = (uint32_t)__builtin_ctz(fl);
         fl &= fl - 1;
         const uint32_t r = b0 + i;
-        const uint32_t mv = mt[r];
+        uint32_t mv = mt[r];
+        if (mv == kUnvisited) {  // the parse stands where no walker searched: the caller redoes the call
+            atomicOr(status, 4u);
+            mv = 0;
+        }
         uint32_t tok;
         if (mv) {
             const uint32_t len = mv >> 16, dist = mv & 0xFFFFu;
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict
 hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint32_t *match, uint64_t base,
                         uint8_t *flag, uint64_t flag_bytes, uint32_t *sub_exit, uint32_t *sub_exit2, uint8_t *merged,
                         uint32_t *tile_cnt, uint32_t *tokens, uint64_t tok_base, uint32_t *ntok, uint32_t *freq,
-                        hipStream_t s) {
+                        uint32_t *status, hipStream_t s) {
     if (c1 <= c0) return hipSuccess;
     const uint32_t nc = c1 - c0;
     const uint32_t spc = parse_subs_per_chunk(g.chunk_bytes);
@@ -381,7 +385,7 @@ hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint
                        tpc, flag, base, tile_cnt);
     hipLaunchKernelGGL(k_emit_scan, dim3(nc), dim3(256), 0, s, tpc, tile_cnt, ntok);
     hipLaunchKernelGGL(k_emit, dim3(tpc, nc), dim3(kEmitThreads), 0, s, g.data, g.first, g.end, g.chunk_bytes, g.chunk_len,
-                       c0, tpc, flag, match, base, tile_cnt, tokens, tok_base, freq);
+                       c0, tpc, flag, match, base, tile_cnt, tokens, tok_base, freq, status);
     return hipGetLastError();
 }
 

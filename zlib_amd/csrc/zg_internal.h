@@ -27,6 +27,11 @@ constexpr uint32_t kMatchTile = 16384;  // positions resolved by one match workg
 constexpr uint32_t kMatchThreads = 1024;
 constexpr uint32_t kMatchRecordTile = 4096;  // tile of the small geometry used for isolated chunks up to this size
 
+// walk kernel: value of match[] at positions no walker stood on (length 0, an impossible distance), and the
+// words of the bit set in which a run of tiles leaves the positions reached beyond its last tile
+constexpr uint32_t kUnvisited = 0x0000FFFFu;
+constexpr uint32_t kWalkExitWords = 10;
+
 // parse / emit kernel geometry
 constexpr uint32_t kParseSub = 512;   // positions per speculative parse sub-tile (> kMaxMatch)
 constexpr uint32_t kEmitTile = 4096;   // positions per unit-emission workgroup
@@ -115,10 +120,19 @@ hipError_t launch_match_lo(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPa
                            const uint16_t *next4, const uint16_t *far3, const uint16_t *next3, uint64_t base,
                            uint32_t *match, uint32_t *open_list, uint32_t *open_far, const uint32_t *open_cnt,
                            hipStream_t s);
+// the search along the greedy parse only (zg_walk.hip): match[] of every position of chunks [c0, c1) of a grid
+// with the general tile geometry -- a result where a walker stood, kUnvisited elsewhere.  exit_bits: kWalkExitWords
+// words per run of tiles_per_run tiles.
+uint32_t walk_tiles_per_run(const ChunkGrid &g, uint32_t n_chunks, uint32_t cus);
+// far4 / next4: the four-byte index; far3 / next3: the three-byte index, read only when mp.min_len == 3.
+hipError_t launch_walk(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *far4,
+                       const uint16_t *next4, const uint16_t *far3, const uint16_t *next3, uint64_t base,
+                       uint32_t *match, uint32_t *exit_bits, uint32_t tiles_per_run, hipStream_t s);
+// status: bit 2 is raised when the parse stands on a position whose match[] is kUnvisited
 hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint32_t *match, uint64_t base,
                         uint8_t *flag, uint64_t flag_bytes, uint32_t *sub_exit, uint32_t *sub_exit2, uint8_t *merged,
                         uint32_t *tile_cnt, uint32_t *tokens, uint64_t tok_base, uint32_t *ntok, uint32_t *freq,
-                        hipStream_t s);
+                        uint32_t *status, hipStream_t s);
 hipError_t launch_histogram(const uint32_t *tokens, uint64_t n, uint32_t *freq, hipStream_t s);
 constexpr int64_t kAllFinal = -2;  // launch_huffman: every chunk's block is the last of its stream
 hipError_t launch_huffman(uint32_t n_chunks, int strategy, const uint32_t *freq, int64_t final_chunk, uint32_t *tab,

@@ -24,6 +24,7 @@
 // with three: the first true member of the FOUR-byte chain, else of the
 // THREE-byte chain.
 #include "zg_internal.h"
+#include "zg_match_util.h"
 
 #include <type_traits>
 
@@ -82,17 +83,6 @@ __device__ __forceinline__ uint32_t hash_at(const uint8_t *__restrict__ data, ui
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
-// Workgroups are dealt round-robin to the eight XCDs, each with an L2 of its own.  Neighbouring tiles (of the match
-// kernels, of the far fix-up) read mostly the same memory, so the block index is turned into a tile index that
-// gives every XCD a contiguous run of tiles: block b runs on XCD b % 8 and takes the (b / 8)-th tile of that XCD's run.
-__device__ __forceinline__ uint32_t xcd_tile_index(uint32_t b, uint32_t n) {
-#ifdef ZG_NO_XCD_REMAP
-    return b;
-#else
-    const uint32_t per = n >> 3, rem = n & 7u, xcd = b & 7u, slot = b >> 3;
-    return xcd * per + (xcd < rem ? xcd : rem) + slot;
-#endif
-}
 
 
 // k_index: the conservative variant.  One wave per segment walks positions in batches of 64, keeping per
@@ -564,78 +554,6 @@ uint64_t index_lookback(uint32_t window) { return window; }
 // tile's bytes plus the preceding window and the forward links of that range
 // are staged in LDS; the threads then claim positions of the tile one by one.
 // ---------------------------------------------------------------------------
-// Geometry of a match workgroup: positions per tile, positions of window staged before them, threads, and how
-// many parked level-2 walks it can hold.  GeomStream is the general one; GeomRecord serves isolated chunks (records) of at most 4 KiB, whose window is
-// the record itself -- a twelfth of the LDS, so that many records are resident per CU.
-#ifndef ZG_LO_STREAM_THREADS
-#define ZG_LO_STREAM_THREADS 1024
-#endif
-template <uint32_t kTileT, uint32_t kWinT, uint32_t kThreadsT, uint32_t kParkedT>
-struct MatchGeom {
-    static constexpr uint32_t tile = kTileT, win = kWinT, threads = kThreadsT, parked = kParkedT;
-    static constexpr uint32_t lo_threads = kThreadsT == 1024 ? ZG_LO_STREAM_THREADS : kThreadsT;  // level 2
-    static constexpr uint32_t data_lds = kWinT + kTileT + 16 + 272;  // 16: alignment slack, 272: look-ahead + pad
-    static constexpr uint32_t next_lds = kWinT + kTileT + 16;
-};
-using GeomStream = MatchGeom<kMatchTile, kMaxWindow, kMatchThreads, 1024>;
-using GeomRecord = MatchGeom<kMatchRecordTile, 0, 256, 64>;
-
-// four bytes at an arbitrary LDS byte offset, from two aligned dwords.  gfx950 also reads an LDS dword at any
-// alignment with one ds_read_b32 (tools/probe/probe_lds_unaligned.hip: correct for every offset), but far more
-// slowly: with it k_match took 9.0 ms instead of 4.1 on 64 MiB of text.
-__device__ __forceinline__ uint32_t lds_ld4(const uint8_t *lds, uint32_t off) {
-    const uint32_t *w = reinterpret_cast<const uint32_t *>(lds + (off & ~3u));
-    const uint32_t lo = w[0], hi = w[1];
-    return __builtin_amdgcn_alignbyte(hi, lo, off & 3u);
-}
-
-// common prefix of the strings at LDS offsets so and po, at most cap bytes
-__device__ __forceinline__ uint32_t lds_lcp(const uint8_t *lds, uint32_t so, uint32_t po, uint32_t cap) {
-    uint32_t m = 0;
-    while (m < cap) {
-        const uint32_t x = lds_ld4(lds, so + m) ^ lds_ld4(lds, po + m);
-        if (x) {
-            m += (uint32_t)__builtin_ctz(x) >> 3;
-            break;
-        }
-        m += 4;
-    }
-    return m < cap ? m : cap;
-}
-
-// copies links [w0, w0 + nlinks) of the view into LDS
-__device__ __forceinline__ void stage_links(const uint16_t *__restrict__ next, uint64_t base, uint64_t w0,
-                                            uint32_t nlinks, uint16_t *s_next, uint32_t tid, uint32_t nthreads) {
-    const uint16_t *src = next + (w0 - base);
-    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
-        uint4 *d4 = reinterpret_cast<uint4 *>(s_next);
-        const uint32_t nv = nlinks >> 3;
-        for (uint32_t i = tid; i < nv; i += nthreads) d4[i] = s4[i];
-        for (uint32_t i = (nv << 3) + tid; i < nlinks; i += nthreads) s_next[i] = src[i];
-    } else {
-        for (uint32_t i = tid; i < nlinks; i += nthreads) s_next[i] = src[i];
-    }
-}
-
-// copies bytes [w0, w0 + nbytes) and links [w0, w0 + nlinks) of the view into LDS
-__device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ data, const uint16_t *__restrict__ next,
-                                           uint64_t base, uint64_t w0, uint32_t nbytes, uint32_t nlinks,
-                                           uint8_t *s_data, uint16_t *s_next, uint32_t tid, uint32_t nthreads,
-                                           uint32_t data_cap) {
-    // stage bytes: 16-byte vectors when the source is aligned, bytes otherwise
-    if (((reinterpret_cast<uintptr_t>(data) + w0) & 15) == 0) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(data + w0);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_data);
-        const uint32_t nv = nbytes >> 4;
-        for (uint32_t i = tid; i < nv; i += nthreads) dst[i] = src[i];
-        for (uint32_t i = (nv << 4) + tid; i < nbytes; i += nthreads) s_data[i] = data[w0 + i];
-    } else {
-        for (uint32_t i = tid; i < nbytes; i += nthreads) s_data[i] = data[w0 + i];
-    }
-    for (uint32_t i = nbytes + tid; i < nbytes + 16 && i < data_cap; i += nthreads) s_data[i] = 0;
-    stage_links(next, base, w0, nlinks, s_next, tid, nthreads);
-}
 
 template <class G>
 __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict__ data, uint64_t first,
@@ -953,25 +871,6 @@ extern "C" int zg_debug_counters(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg));
 }
 #endif
-// The sixteen candidates a .. a + 15 (a a multiple of 16) against the four bytes p0: the lowest j whose candidate
-// agrees in four (kFull) or three bytes, 16 if none.  kEdge also keeps candidates inside [lo, hi).
-template <bool kEdge, bool kFull>
-__device__ __forceinline__ uint32_t scan16(const uint8_t *s_data, uint32_t a, uint32_t p0, uint32_t lo, uint32_t hi) {
-    uint32_t h = 16u;
-    if (kEdge && a >= hi) return h;
-    const uint4 q = *reinterpret_cast<const uint4 *>(s_data + a);
-    const uint32_t w[5] = {q.x, q.y, q.z, q.w, *reinterpret_cast<const uint32_t *>(s_data + a + 16)};
-    const uint32_t want = kFull ? p0 : (p0 & 0x00FFFFFFu);
-#pragma unroll
-    for (int j = 15; j >= 0; j--) {
-        uint32_t v = (j & 3) == 0 ? w[j >> 2] : __builtin_amdgcn_alignbyte(w[(j >> 2) + 1], w[j >> 2], (uint32_t)(j & 3));
-        if (!kFull) v &= 0x00FFFFFFu;
-        bool eq = v == want;
-        if (kEdge) eq = eq && a + (uint32_t)j >= lo && a + (uint32_t)j < hi;
-        h = eq ? (uint32_t)j : h;
-    }
-    return h;
-}
 
 // A walk that has used up its step budget (a rare key sharing its bucket with a frequent one: thousands of
 // members, one lane busy while the rest of the tile has finished) is parked -- (list index, cursor) in s_park --
