@@ -131,8 +131,9 @@ def measured_traffic(workload, kernel):
         return None
 
 
-def cpu_baseline(za, kind, seed, total, chunk):
-    """The reference algorithm (oracle, verbatim exhaustive matcher) on this host's cores, on a bounded sample."""
+def cpu_baseline(za, kind, seed, total, chunk, torch=None, ctx=None, device=None):
+    """The reference algorithm (oracle, verbatim exhaustive matcher) on this host's cores, on a bounded sample; and
+    this library on the SAME slices (each one block with its 32 KiB window), for the compression ratio side by side."""
     from oracle import zref
     cores = min(16, len(os.sched_getaffinity(0)))
     slice_len = 768 * 1024 if kind == "text" else 160 * 1024
@@ -154,7 +155,18 @@ def cpu_baseline(za, kind, seed, total, chunk):
     bits = zref.bench_slices(data, slices, cores)
     dt = time.perf_counter() - t0
     nbytes = slice_len * len(slices)
+    same = {}
+    if torch is not None:
+        gpu_bits = []
+        for blob, (_, _, halo) in zip(blobs, slices):
+            d = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+            info = za.shard_begin(d.data_ptr(), halo, slice_len, za.Strategy.Dynamic, True, chunk_bytes=slice_len, ctx=ctx)
+            gpu_bits.append(int(info.total_bits))
+        ref_ratio, own_ratio = sum(bits) / 8 / nbytes, sum(gpu_bits) / 8 / nbytes
+        same = {"build_ratio_same_slices": own_ratio, "ratio_delta": own_ratio / ref_ratio - 1.0,
+                "slices_with_identical_bit_count": sum(a == b for a, b in zip(bits, gpu_bits))}
     return {
+        **same,
         "value": nbytes / dt / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
         "sample": f"{len(slices)} slices of {slice_len // 1024} KiB (each with its 32 KiB window) spread over the "
                   f"corpus, one thread per slice, {dt:.1f} s wall; reference-style single Dynamic block per slice",
@@ -313,7 +325,7 @@ def main():
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
         }
         if world == 1 and not args.no_cpu_baseline and strat_name == "Dynamic" and not batch:
-            line["cpu_baseline"] = cpu_baseline(za, kind, seed, total, chunk)
+            line["cpu_baseline"] = cpu_baseline(za, kind, seed, total, chunk, torch, ctx, device)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

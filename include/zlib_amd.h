@@ -86,6 +86,16 @@ size_t zg_compress_bound(size_t n, int strategy, const zg_opts *opts);
 int zg_compress_device(zg_ctx *ctx, const void *d_in, size_t n, int strategy, const zg_opts *opts,
                        void *d_out, size_t out_cap, size_t *out_n);
 
+/* Where the blocks of the last zg_compress, zg_compress_device (Dynamic / Fixed)
+ * or zg_shard_begin call on this ctx start: bit_offsets[i] receives the bit
+ * offset of chunk i's block in that call's output (zg_shard_begin: counted from
+ * the rank's first block).  Returns the number of blocks; at most cap entries
+ * are written.  No counterpart in the reference, whose streams have one block;
+ * a reader that wants to inflate the blocks of a stream in parallel needs
+ * these (they are not part of the stream), and the tests use them to compare
+ * single blocks of very large streams with the oracle's. */
+size_t zg_last_block_offsets(zg_ctx *ctx, uint64_t *bit_offsets, size_t cap);
+
 /* ---- many records, each a zlib stream of its own ----
  * compress(record, strategy) of the reference (src/compress.rs:51-86) for every
  * record of a batch at once: record i is in[offsets[i] .. offsets[i+1]), its

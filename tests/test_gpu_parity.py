@@ -413,3 +413,41 @@ def test_one_chunk_of_the_accepted_maximum(za):
         assert out == data[pos:pos + len(out)]
         pos += len(out)
     assert pos == n and d.eof
+
+
+def test_blocks_inside_a_very_large_input_equal_the_oracle(za, z):
+    """576 MiB of the mixed corpus in one call: three passes over the scratch buffers (256 MiB each) and several
+    thousand index segments.  Chunks next to the pass seams, at both ends and in between are compared bit for
+    bit with the block the oracle writes for that chunk and its 32 KiB window; the stream as a whole inflates."""
+    import torch
+    chunk, n_chunks = 1 << 20, 576
+    n = chunk * n_chunks
+    data = za.corpus("mixed", n, seed=0x5EED0004)
+    d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    cap = za.compress_bound(n, za.Strategy.Dynamic, chunk_bytes=chunk)
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    ctx = za.default_context()
+    out_n = za.compress_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, za.Strategy.Dynamic, chunk_bytes=chunk, ctx=ctx)
+    stream = d_out[:out_n].cpu().numpy().tobytes()
+    del d_in, d_out
+    offs = za.last_block_offsets(ctx=ctx)
+    assert len(offs) == n_chunks and offs[0] == 16 and all(a < b for a, b in zip(offs, offs[1:]))
+    end_bits = (out_n - 4) * 8  # the last block ends within the last byte before the Adler-32
+    for c in (0, 1, 2, 3, 100, 254, 255, 256, 257, 258, 259, 383, 510, 511, 512, 513, 514, 515, 574, 575):
+        toks = z.chunk_tokens(data, chunk, c, fast=True)
+        want, bits = z.write_block(toks, z.DYNAMIC, c == n_chunks - 1)
+        nxt = offs[c + 1] if c + 1 < n_chunks else None
+        if nxt is not None:
+            assert nxt - offs[c] == bits, f"chunk {c}: block of {nxt - offs[c]} bits, the oracle's has {bits}"
+        else:
+            assert end_bits - 7 <= offs[c] + bits <= end_bits
+        lo, sh = offs[c] // 8, offs[c] % 8
+        got = (int.from_bytes(stream[lo:lo + (bits + sh + 7) // 8 + 1], "little") >> sh) & ((1 << bits) - 1)
+        assert got == int.from_bytes(want, "little") & ((1 << bits) - 1), f"chunk {c}: block differs from the oracle's"
+    d = sysz.decompressobj()
+    pos = 0
+    for at in range(0, len(stream), 16 << 20):
+        out = d.decompress(stream[at:at + (16 << 20)])
+        assert out == data[pos:pos + len(out)]
+        pos += len(out)
+    assert pos == n and d.eof

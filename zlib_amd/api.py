@@ -131,6 +131,15 @@ def compress_device(d_in: int, n: int, d_out: int, out_cap: int, strategy: Strat
     return n_out.value
 
 
+def last_block_offsets(*, ctx: Optional[Context] = None) -> List[int]:
+    """Bit offsets of the blocks written by the last compress / compress_device / shard_begin call on ctx."""
+    ctx = ctx or default_context()
+    n = _lib.lib().zg_last_block_offsets(ctx.handle, None, 0)
+    buf = (C.c_uint64 * max(1, n))()
+    _lib.lib().zg_last_block_offsets(ctx.handle, buf, n)
+    return [int(buf[i]) for i in range(n)]
+
+
 def compress_batch(records: Sequence[bytes], strategy: Strategy = Strategy.Dynamic, *,
                    ctx: Optional[Context] = None) -> List[bytes]:
     """[zlib::compress(r, &strategy) for r in records], all records in flight on the GPU at once."""

@@ -90,6 +90,8 @@ struct zg_ctx {
     // set should the parse ever stand on an unsearched position (never seen; the check is cheap).
     bool walk_off = true;
     int cus = 256;
+    // bit offset of every block written by the last zg_compress(_device) / zg_shard_begin call (zg_last_block_offsets)
+    std::vector<uint64_t> block_offs;
     // profiling
     bool prof = false;
     struct Ev {
@@ -334,6 +336,15 @@ int run_back(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, uint32_t m
     return ZG_OK;
 }
 
+// keeps the bit offsets of blocks [c0, c1) of the current call on the host (the vector has its final size already:
+// the copy is asynchronous and completes with the call's last synchronisation)
+int keep_block_offsets(zg_ctx *c, uint32_t c0, uint32_t c1) {
+    if (c->block_offs.size() < c1) return ZG_OK;
+    HIPCHK(hipMemcpyAsync(c->block_offs.data() + c0, c->bit_off.p, (size_t)(c1 - c0) * sizeof(uint64_t),
+                          hipMemcpyDeviceToHost, c->stream));
+    return ZG_OK;
+}
+
 // Adler-32 of data[0..n) folded into the running state
 int run_adler(zg_ctx *c, const uint8_t *data, uint64_t n) {
     if (!n) return ZG_OK;
@@ -410,6 +421,7 @@ int compress_device_once(zg_ctx *c, const uint8_t *d_in, size_t n, int strategy,
     if (rc) return rc;
     Scalars *sc = c->scalars.as<Scalars>();
 
+    c->block_offs.clear();
     if (strategy == ZG_RAW) {
         rc = upload(n);
         if (rc) return rc;
@@ -436,6 +448,11 @@ int compress_device_once(zg_ctx *c, const uint8_t *d_in, size_t n, int strategy,
         rc = ensure_chunk_meta(c, bc, max_tiles);
         if (rc) return rc;
         const size_t bound = zg_compress_bound(n, strategy, opts);
+        try {
+            c->block_offs.assign(g.n_chunks, 0);
+        } catch (...) {
+            return ZG_ERR_NOMEM;
+        }
         LAUNCH(K_MISC, hipMemsetAsync(d_out, 0, bound, c->stream));
         const MatchParams mp{kMaxWindow, 3, 258};  // get_zlib_compressor, src/compress.rs:451-456
         rc = upload((size_t)std::min<uint64_t>(g.n_chunks, bc) * plan.chunk_bytes);
@@ -446,6 +463,8 @@ int compress_device_once(zg_ctx *c, const uint8_t *d_in, size_t n, int strategy,
             rc = run_front(c, g, c0, c1, mp, strategy, final_chunk, true);
             if (rc) return rc;
             rc = run_back(c, g, c0, c1, max_tiles, reinterpret_cast<uint32_t *>(d_out), (uint64_t)(bound - 4) * 8);
+            if (rc) return rc;
+            rc = keep_block_offsets(c, c0, c1);
             if (rc) return rc;
             // the next batch's bytes travel while this batch's kernels run
             rc = upload(((size_t)c1 + bc) * plan.chunk_bytes);
@@ -1122,6 +1141,11 @@ int zg_shard_begin(zg_ctx *ctx, const void *d_in, size_t halo, size_t n, int str
         HIPCHK(c->shard_buf.ensure(bound + 8));
         rc = init_scalars(c, 0);
         if (rc) return rc;
+        try {
+            c->block_offs.assign(g.n_chunks, 0);
+        } catch (...) {
+            return ZG_ERR_NOMEM;
+        }
         LAUNCH(K_MISC, hipMemsetAsync(c->shard_buf.p, 0, bound + 8, c->stream));
         for (uint32_t c0 = 0; c0 < g.n_chunks; c0 += (uint32_t)bc) {
             const uint32_t c1 = (uint32_t)std::min<uint64_t>(g.n_chunks, (uint64_t)c0 + bc);
@@ -1129,6 +1153,8 @@ int zg_shard_begin(zg_ctx *ctx, const void *d_in, size_t halo, size_t n, int str
             rc = run_front(c, g, c0, c1, mp, strategy, final_chunk, true);
             if (rc) return rc;
             rc = run_back(c, g, c0, c1, max_tiles, c->shard_buf.as<uint32_t>(), (uint64_t)bound * 8);
+            if (rc) return rc;
+            rc = keep_block_offsets(c, c0, c1);
             if (rc) return rc;
         }
         rc = run_adler(c, g.data + halo, n);
@@ -1202,6 +1228,17 @@ int zg_shard_finish(zg_ctx *ctx, uint64_t base_bit, int first_rank, int last_ran
     if (h.status & 1u) return ZG_ERR_CAPACITY;
     *out_bytes = (size_t)h.out_bytes;
     return ZG_OK;
+}
+
+size_t zg_last_block_offsets(zg_ctx *ctx, uint64_t *bit_offsets, size_t cap) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t n = c->block_offs.size();
+    if (bit_offsets)
+        for (size_t i = 0; i < n && i < cap; i++) bit_offsets[i] = c->block_offs[i];
+    return n;
 }
 
 int zg_profile_enable(zg_ctx *ctx, int on) {
