@@ -86,6 +86,17 @@ size_t zg_compress_bound(size_t n, int strategy, const zg_opts *opts);
 int zg_compress_device(zg_ctx *ctx, const void *d_in, size_t n, int strategy, const zg_opts *opts,
                        void *d_out, size_t out_cap, size_t *out_n);
 
+/* The same call spread over several GPUs of one process: zlib::compress
+ * (src/compress.rs:51-86) for a caller that owns more than one device.  The
+ * input is cut into contiguous runs of whole chunks, one per entry of `devices`
+ * (HIP device indices; an index may appear more than once), every device
+ * compresses its run on a context the library keeps, and the blocks are
+ * assembled into ONE stream, byte for byte the stream zg_compress returns for
+ * the same input and options.  Host buffers in and out; *out is malloc'ed
+ * (zg_free).  Calls are serialised by a lock of their own. */
+int zg_compress_multi(const int *devices, int n_devices, const uint8_t *in, size_t n, int strategy,
+                      const zg_opts *opts, uint8_t **out, size_t *out_n);
+
 /* Where the blocks of the last zg_compress, zg_compress_device (Dynamic / Fixed)
  * or zg_shard_begin call on this ctx start: bit_offsets[i] receives the bit
  * offset of chunk i's block in that call's output (zg_shard_begin: counted from

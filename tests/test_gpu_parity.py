@@ -155,6 +155,20 @@ def test_conservative_index_kernel(za, z, monkeypatch):
         ctx.close()
 
 
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0] * 5])
+def test_several_devices_in_one_process_give_the_single_device_stream(za, devices):
+    """zg_compress_multi with the one GPU of the box standing in for several (a context per run): the assembled
+    stream is the single-context stream, whatever the bit phase at which the runs meet."""
+    for data, chunk in ((za.corpus("mixed", (5 << 20) + 12345, seed=21), 1 << 16), (za.corpus("text", 700_001, seed=22), 1 << 17),
+                        (za.corpus("text", 100_000, seed=23), 1 << 20), (b"", 1 << 20), (za.corpus("binary", 3 << 16, seed=24), 1 << 16)):
+        for strategy in (za.Strategy.Dynamic, za.Strategy.Fixed):
+            got = za.compress_multi(data, devices, strategy, chunk_bytes=chunk)
+            _same(got, za.compress(data, strategy, chunk_bytes=chunk), f"{len(data)} bytes over {len(devices)} runs")
+            assert sysz.decompress(got) == data
+    assert za.compress_multi(b"abc" * 5000, devices, za.Strategy.Raw) == za.compress(b"abc" * 5000, za.Strategy.Raw)
+    assert sysz.decompress(za.compress_multi(za.corpus("text", 300_000), devices, za.Strategy.Auto)) == za.corpus("text", 300_000)
+
+
 def test_search_along_the_parse(za, z, monkeypatch):
     """The optional search that visits only the positions the greedy parse can reach (k_walk; four-byte chains
     in LDS, three-byte chains beside them) gives the streams and units of the full search."""

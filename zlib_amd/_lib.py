@@ -18,7 +18,7 @@ ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_I
 #: every symbol include/zlib_amd.h declares
 SYMBOLS = [
     "zg_init", "zg_destroy", "zg_strerror", "zg_last_error", "zg_free", "zg_compress", "zg_compress_bound",
-    "zg_compress_device", "zg_last_block_offsets", "zg_compress_batch", "zg_compress_batch_bound", "zg_compress_batch_device",
+    "zg_compress_device", "zg_compress_multi", "zg_last_block_offsets", "zg_compress_batch", "zg_compress_batch_bound", "zg_compress_batch_device",
     "zg_decompress", "zg_decompress_batch", "zg_decompress_batch_device", "zg_shard_begin", "zg_shard_finish", "zg_adler32_combine", "zg_adler32",
     "zg_adler32_device", "zg_adler32_device_noalloc", "zg_lz77", "zg_huffman_from_tokens", "zg_profile_enable", "zg_profile_reset",
     "zg_profile_count", "zg_profile_get", "zg_corpus_fill",
@@ -72,6 +72,8 @@ def _declare(L):
     f("zg_compress", C.c_int, vp, C.c_char_p, sz, C.c_int, C.POINTER(Opts), C.POINTER(u8p), C.POINTER(sz))
     f("zg_compress_bound", sz, sz, C.c_int, C.POINTER(Opts))
     f("zg_compress_device", C.c_int, vp, vp, sz, C.c_int, C.POINTER(Opts), vp, sz, C.POINTER(sz))
+    f("zg_compress_multi", C.c_int, C.POINTER(C.c_int), C.c_int, C.c_char_p, sz, C.c_int, C.POINTER(Opts),
+      C.POINTER(u8p), C.POINTER(sz))
     f("zg_last_block_offsets", sz, vp, C.POINTER(C.c_uint64), sz)
     f("zg_compress_batch", C.c_int, vp, C.c_char_p, C.POINTER(sz), sz, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
       C.POINTER(C.POINTER(sz)))

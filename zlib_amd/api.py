@@ -131,6 +131,22 @@ def compress_device(d_in: int, n: int, d_out: int, out_cap: int, strategy: Strat
     return n_out.value
 
 
+def compress_multi(data: bytes, devices: Sequence[int], strategy: Strategy = Strategy.Dynamic, *, chunk_bytes: int = 0,
+                   batch_bytes: int = 0) -> bytes:
+    """zlib::compress(&data, &strategy) on several GPUs of this process: one run of chunks per entry of `devices`."""
+    data = bytes(data)
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    o = _opts(chunk_bytes, batch_bytes)
+    devs = (C.c_int * max(1, len(devices)))(*devices)
+    rc = _lib.lib().zg_compress_multi(devs, len(devices), data, len(data), int(strategy), C.byref(o), C.byref(out), C.byref(n))
+    if rc:
+        raise ZgError(rc)
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        _lib.lib().zg_free(out)
+
+
 def last_block_offsets(*, ctx: Optional[Context] = None) -> List[int]:
     """Bit offsets of the blocks written by the last compress / compress_device / shard_begin call on ctx."""
     ctx = ctx or default_context()

@@ -1230,6 +1230,144 @@ int zg_shard_finish(zg_ctx *ctx, uint64_t base_bit, int first_rank, int last_ran
     return ZG_OK;
 }
 
+// ---------------------------------------------------------------------------
+// zg_compress_multi: one stream from several GPUs, driven from one process.  The input is cut into contiguous runs
+// of whole chunks, one run per device (zg_shard_begin on a context of its own, one host thread per device); the
+// three integers per run that fix the layout of the stream are exchanged on the host; every device then moves
+// its blocks to their bit phase (zg_shard_finish) and copies them straight into its own byte range of the result.
+// Two neighbouring runs share at most one byte, which is merged on the host afterwards.
+// ---------------------------------------------------------------------------
+namespace {
+std::mutex g_multi_mu;
+std::vector<zg_ctx *> g_multi_ctx;  // context of run r, kept between calls
+
+struct MultiRun {
+    zg_ctx *c = nullptr;
+    size_t start = 0, n = 0, halo = 0;
+    zg_shard_info info{};
+    uint64_t base_bit = 0;
+    size_t nb = 0;         // bytes of the run at its bit phase
+    uint8_t first_byte = 0;
+    int rc = ZG_OK;
+};
+
+int multi_begin(MultiRun &r, const uint8_t *in, int strategy, const zg_opts *opts, bool last) {
+    zg_ctx *c = r.c;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(c->stage_in.ensure(r.halo + r.n + 64));
+        if (r.halo + r.n)
+            HIPCHK(hipMemcpyAsync(c->stage_in.p, in + r.start - r.halo, r.halo + r.n, hipMemcpyHostToDevice, c->stream));
+    }
+    return zg_shard_begin(c, c->stage_in.p, r.halo, r.n, strategy, opts, last ? 1 : 0, &r.info);
+}
+
+int multi_finish(MultiRun &r, bool first, bool last, uint32_t adler, uint8_t *out, size_t out_total) {
+    zg_ctx *c = r.c;
+    const uint64_t local0 = first ? 16 : (r.base_bit & 7);
+    const size_t need = (size_t)(((local0 + r.info.total_bits + 7) >> 3) + (last ? 4 : 0));
+    const size_t cap = (need + 3 + 8) & ~(size_t)3;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(c->stage_out.ensure(cap));
+    }
+    int rc = zg_shard_finish(c, r.base_bit, first ? 1 : 0, last ? 1 : 0, adler, c->stage_out.p, cap, &r.nb);
+    if (rc) return rc;
+    const size_t off = first ? 0 : (size_t)(r.base_bit >> 3);
+    if (off + r.nb > out_total || r.nb == 0) return ZG_ERR_INTERNAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    // the first byte may be shared with the run before: it is merged by the caller once every run has landed
+    HIPCHK(hipMemcpy(&r.first_byte, c->stage_out.p, 1, hipMemcpyDeviceToHost));
+    if (r.nb > 1)
+        HIPCHK(hipMemcpy(out + off + 1, c->stage_out.as<uint8_t>() + 1, r.nb - 1, hipMemcpyDeviceToHost));
+    return ZG_OK;
+}
+}  // namespace
+
+int zg_compress_multi(const int *devices, int n_devices, const uint8_t *in, size_t n, int strategy,
+                      const zg_opts *opts, uint8_t **out, size_t *out_n) {
+    if (!devices || n_devices < 1 || n_devices > 64 || !out || !out_n || (!in && n)) return ZG_ERR_ARG;
+    Plan plan;
+    int rc = make_plan(opts, &plan);
+    if (rc) return rc;
+    if (strategy == ZG_AUTO) strategy = auto_choice(in, n);
+    if (strategy < ZG_AUTO || strategy > ZG_RAW) return ZG_ERR_ARG;
+    std::lock_guard<std::mutex> guard(g_multi_mu);
+    auto ctx_of = [&](size_t r, int device, zg_ctx **c) -> int {
+        if (g_multi_ctx.size() <= r) g_multi_ctx.resize(r + 1, nullptr);
+        if (g_multi_ctx[r] && g_multi_ctx[r]->device != device) {
+            zg_destroy(g_multi_ctx[r]);
+            g_multi_ctx[r] = nullptr;
+        }
+        if (!g_multi_ctx[r]) {
+            const int e = zg_init(device, &g_multi_ctx[r]);
+            if (e) return e;
+        }
+        *c = g_multi_ctx[r];
+        return ZG_OK;
+    };
+    const size_t n_chunks = n == 0 ? 1 : (n + plan.chunk_bytes - 1) / plan.chunk_bytes;
+    const size_t n_runs = std::min<size_t>((size_t)n_devices, n_chunks);
+    if (strategy == ZG_RAW || n_runs == 1) {  // stored blocks are a plain copy; a single run needs no assembly
+        zg_ctx *c = nullptr;
+        rc = ctx_of(0, devices[0], &c);
+        return rc ? rc : zg_compress(c, in, n, strategy, opts, out, out_n);
+    }
+    std::vector<MultiRun> runs(n_runs);
+    for (size_t r = 0; r < n_runs; r++) {
+        rc = ctx_of(r, devices[r], &runs[r].c);
+        if (rc) return rc;
+        const size_t c0 = r * n_chunks / n_runs, c1 = (r + 1) * n_chunks / n_runs;
+        runs[r].start = std::min(n, c0 * plan.chunk_bytes);
+        runs[r].n = std::min(n, c1 * plan.chunk_bytes) - runs[r].start;
+        runs[r].halo = std::min<size_t>(kMaxWindow, runs[r].start);
+    }
+    auto in_parallel = [&](auto &&fn) -> int {
+        std::vector<std::thread> pool;
+        try {
+            for (size_t r = 1; r < n_runs; r++) pool.emplace_back([&, r] { runs[r].rc = fn(runs[r], r); });
+        } catch (...) {  // no more threads to be had: the remaining runs take their turn on this one
+            for (size_t r = pool.size() + 1; r < n_runs; r++) runs[r].rc = fn(runs[r], r);
+        }
+        runs[0].rc = fn(runs[0], 0);
+        for (auto &t : pool) t.join();
+        for (auto &r : runs)
+            if (r.rc) return r.rc;
+        return ZG_OK;
+    };
+    rc = in_parallel([&](MultiRun &r, size_t i) { return multi_begin(r, in, strategy, opts, i + 1 == n_runs); });
+    if (rc) return rc;
+    // the layout of the stream: 16 header bits, the runs' blocks back to back, padding to a byte, the Adler-32
+    uint64_t bit = 16;
+    uint32_t adler = 1;
+    for (auto &r : runs) {
+        r.base_bit = bit;
+        bit += r.info.total_bits;
+        adler = zg_adler32_combine(adler, r.info.adler, r.n);
+    }
+    const size_t total = (size_t)((bit + 7) >> 3) + 4;
+    uint8_t *h = static_cast<uint8_t *>(malloc(total));
+    if (!h) return ZG_ERR_NOMEM;
+    rc = in_parallel([&](MultiRun &r, size_t i) { return multi_finish(r, i == 0, i + 1 == n_runs, adler, h, total); });
+    if (rc) {
+        free(h);
+        return rc;
+    }
+    for (size_t i = 0; i < n_runs; i++) {  // in order: a run's first byte joins the previous run's last
+        const size_t off = i == 0 ? 0 : (size_t)(runs[i].base_bit >> 3);
+        if (i != 0 && (runs[i].base_bit & 7))
+            h[off] |= runs[i].first_byte;
+        else
+            h[off] = runs[i].first_byte;
+    }
+    *out = h;
+    *out_n = total;
+    return ZG_OK;
+}
+
 size_t zg_last_block_offsets(zg_ctx *ctx, uint64_t *bit_offsets, size_t cap) {
     int rc = 0;
     zg_ctx *c = resolve(ctx, &rc);
