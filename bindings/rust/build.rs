@@ -5,5 +5,6 @@ fn main() {
     let dir = std::env::var("ZLIB_AMD_LIB_DIR").expect("set ZLIB_AMD_LIB_DIR to the directory of libzlib_amd.so");
     println!("cargo:rustc-link-search=native={dir}");
     println!("cargo:rustc-link-lib=dylib=zlib_amd");
+    println!("cargo:rustc-link-arg=-Wl,-rpath,{dir}");
     println!("cargo:rerun-if-env-changed=ZLIB_AMD_LIB_DIR");
 }

@@ -1,4 +1,4 @@
-//! Declarations of include/zlib_amd.h (the C ABI), entry points of the compress path only.
+//! Declarations of include/zlib_amd.h (the C ABI): the entry points this crate calls.
 use std::os::raw::{c_char, c_int, c_void};
 
 #[repr(C)]
@@ -15,6 +15,8 @@ extern "C" {
     pub fn zg_free(p: *mut c_void);
     pub fn zg_compress(ctx: *mut c_void, input: *const u8, n: usize, strategy: c_int, opts: *const ZgOpts,
                        out: *mut *mut u8, out_n: *mut usize) -> c_int;
+    pub fn zg_compress_multi(devices: *const c_int, n_devices: c_int, input: *const u8, n: usize, strategy: c_int,
+                             opts: *const ZgOpts, out: *mut *mut u8, out_n: *mut usize) -> c_int;
     pub fn zg_compress_batch(ctx: *mut c_void, input: *const u8, offsets: *const usize, n_records: usize,
                              strategy: c_int, out: *mut *mut u8, out_offsets: *mut *mut usize) -> c_int;
     pub fn zg_decompress(ctx: *mut c_void, input: *const u8, n: usize, out: *mut *mut u8, out_n: *mut usize) -> c_int;

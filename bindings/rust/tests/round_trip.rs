@@ -1,0 +1,78 @@
+//! The crate's integration test (reference tests/test_zlib.rs:30-115: compress -> decompress identity with Fixed,
+//! Dynamic and Auto on LICENSE and on every file under src/) against this shim.  The inputs are generated here --
+//! text of a licence's size and source-like text of the sizes of the crate's files (167 B ... 35 875 B) -- not
+//! copied from the crate.
+use zlib_amd_shim::huffman::HuffmanTree;
+use zlib_amd_shim::lz77::{LZ77Compressor, LZ77Unit};
+use zlib_amd_shim::{compress, decompress, Strategy};
+
+fn words(seed: u64, n: usize) -> Vec<u8> {
+    let vocab = [
+        "fn", "let", "mut", "pub", "self", "usize", "return", "match", "impl", "the", "of", "and", "to", "in",
+        "permission", "software", "without", "warranty", "copyright", "notice", "shall", "be", "included",
+    ];
+    let (mut s, mut out) = (seed | 1, Vec::with_capacity(n + 16));
+    while out.len() < n {
+        s ^= s << 13;
+        s ^= s >> 7;
+        s ^= s << 17;
+        out.extend_from_slice(vocab[(s % vocab.len() as u64) as usize].as_bytes());
+        out.push(if s % 11 == 0 { b'\n' } else { b' ' });
+    }
+    out.truncate(n);
+    out
+}
+
+fn inputs() -> Vec<Vec<u8>> {
+    // LICENSE (1081 B) and the sizes of the files under src/
+    [1081usize, 167, 327, 4705, 6141, 10324, 13939, 30522, 35875].iter().enumerate().map(|(i, &n)| words(i as u64 + 7, n)).collect()
+}
+
+fn round_trip(strategy: &Strategy) {
+    for bytes in inputs() {
+        let compressed = compress(&bytes, strategy);
+        let decompressed = decompress(&compressed).expect("Correct decompression");
+        assert_eq!(bytes, decompressed);
+        // the crate's own decoder reads the same stream
+        assert_eq!(zlib::decompress(&compressed).expect("Correct decompression"), bytes);
+    }
+}
+
+#[test]
+fn test_fixed() {
+    round_trip(&Strategy::Fixed);
+}
+
+#[test]
+fn test_dynamic() {
+    round_trip(&Strategy::Dynamic);
+}
+
+#[test]
+fn test_auto() {
+    round_trip(&Strategy::Auto);
+}
+
+#[test]
+fn test_units_and_trees_equal_the_crates_own() {
+    let data = words(99, 20_000);
+    let mut own = zlib::lz77::LZ77Compressor::with_window_size(1 << 15);
+    own.min_match_length = 3;
+    own.max_match_length = 258;
+    let mut gpu = LZ77Compressor::with_window_size(1 << 15);
+    gpu.min_match_length = 3;
+    gpu.max_match_length = 258;
+    let units: Vec<LZ77Unit> = gpu.compress(&data);
+    assert_eq!(units, own.compress(&data));
+    assert_eq!(LZ77Compressor::with_window_size((1 << 15) + 1).window_size, 1 << 15);
+    // code lengths: equal to the crate's whenever its heap meets no tie between internal nodes; always of the
+    // same total cost
+    let (mut lt, mut dt) = HuffmanTree::from_lz77(&units, &gpu);
+    lt.assign();
+    dt.assign();
+    let (mut lo, mut d_o) = zlib::huffman::HuffmanTree::from_lz77(&units, &own);
+    lo.assign();
+    d_o.assign();
+    assert_eq!(lt.encodings().unwrap().len(), lo.encodings().unwrap().len());
+    assert_eq!(dt.encodings().unwrap().len(), d_o.encodings().unwrap().len());
+}

@@ -223,3 +223,17 @@ def test_reference_file_sizes_match_survey():
         assert abs(len(z.compress_reference(data, z.DYNAMIC)) - dyn) <= 4
     lic = open(os.path.join(REF, "LICENSE"), "rb").read()
     assert len(z.compress_reference(lic, z.FIXED)) == 819
+
+
+def test_config_0_one_mib_of_text_fixed_on_the_cpu():
+    """The baseline's first configuration: compress + decompress 1 MiB of synthetic text, Strategy::Fixed, on the
+    CPU with the restatement of the reference (verbatim exhaustive matcher, about half a minute on one core):
+    the round trip through the restated decoder and through system zlib, and the indexed matcher giving the very
+    same stream."""
+    import zlib_amd as za  # host-side corpus generator only
+    data = za.corpus("text", 1 << 20, seed=0x5EED0001)
+    stream = z.compress_reference(data, z.FIXED)
+    assert stream[:2] == b"\x78\x01" and 0.45 < len(stream) / len(data) < 0.55
+    assert z.decompress(stream) == data
+    assert sysz.decompress(stream) == data
+    assert z.compress_chunked(data, z.FIXED, 1 << 20, fast=True) == stream
