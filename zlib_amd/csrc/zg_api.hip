@@ -78,17 +78,20 @@ struct zg_ctx {
     hipStream_t copy = nullptr;  // uploads of host input, overlapped with the kernels on `stream`
     std::mutex mu;
     std::string err;
-    DevBuf walk_exit, shard_buf, far, next, far4, next4, far3, next3, open_list, open_far, open_cnt, rec_len, rec_off, inf_off, inf_len, inf_status, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
+    DevBuf walk_exit, walk_chunk, shard_buf, far, next, far4, next4, far3, next3, open_list, open_far, open_cnt, rec_len, rec_off, inf_off, inf_len, inf_status, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
         scalars, stage_in, stage_out, misc, flag, sub_exit, sub_exit2, merged, tile_cnt, adler_blk;
     // shard state kept between zg_shard_begin and zg_shard_finish
     bool shard_active = false;
     uint64_t shard_total_bits = 0;
     // set once the exchange-based index kernel has reported an out-of-order exchange: use k_index from then on
     bool index_safe = false;
-    // The search along the parse only (k_walk) is chosen per context (ZLIB_AMD_WALK=1); the default searches every
-    // position (k_match, k_match_lo), which is faster on text-like and incompressible input.  walk_off also is
-    // set should the parse ever stand on an unsearched position (never seen; the check is cheap).
-    bool walk_off = true;
+    // How a chunk's matches are found: kWalkAuto (default) samples the chunk's five-byte chains and sends chunks
+    // with long chains (structured data) to the search along the parse (k_walk), the others to the search of
+    // every position (k_match, k_match_lo), which is faster on text-like and incompressible input;
+    // ZLIB_AMD_WALK=1 / 0 forces one way for every chunk.  walk_off is also set should the parse ever stand on an
+    // unsearched position (never seen; the check is cheap).
+    int walk_mode = 2;  // 0 never, 1 always, 2 by probe
+    bool walk_off = false;
     int cus = 256;
     // bit offset of every block written by the last zg_compress(_device) / zg_shard_begin call (zg_last_block_offsets)
     std::vector<uint64_t> block_offs;
@@ -245,10 +248,13 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
     // Two ways to the match of every position the parse stands on.  The walk (k_walk): the search runs along the
     // parse only, on the four-byte chains, with the three-byte chains beside it for lengths of three.  The full
     // search (k_match, k_match_lo): every position, five-byte chains first, then four- and three-byte chains for
-    // the positions left open; it serves small records and stands in should the walk's check ever fail.
-    const bool walk = !c->walk_off && match_tile_positions(g) == kMatchTile;
+    // the positions left open; it also serves small records and stands in should the walk's check ever fail.
     const bool two_level = mp.min_len < 5;  // full search: lengths 3 and 4 need the shorter chains
-    const bool need5 = !walk, need4 = walk || two_level, need3 = walk ? mp.min_len < 4 : two_level;
+    const bool can_walk = !c->walk_off && match_tile_positions(g) == kMatchTile;
+    const bool walk_all = can_walk && c->walk_mode == 1;
+    const bool walk_some = can_walk && c->walk_mode == 2 && two_level;  // chunk by chunk, after a look at the chains
+    const bool walk = walk_all || walk_some, full = !walk_all;
+    const bool need5 = full, need4 = walk || two_level, need3 = (walk && mp.min_len < 4) || (full && two_level);
     const uint32_t rec_min = mp.min_len < 5 ? 5u : mp.min_len;
     if (need5) {
         HIPCHK(c->far.ensure(span * 2 + 64));
@@ -270,7 +276,7 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
         if (need5) set.add(5, c->far.as<uint16_t>(), c->next.as<uint16_t>());
         if (need4) set.add(4, c->far4.as<uint16_t>(), c->next4.as<uint16_t>());
         if (need3) set.add(3, c->far3.as<uint16_t>(), c->next3.as<uint16_t>());
-        if (two_level && !walk) {
+        if (two_level && full) {
             const uint64_t ntiles = (uint64_t)(c1 - c0) * match_tiles_per_chunk(g);
             HIPCHK(c->open_list.ensure(ntiles * match_tile_positions(g) * sizeof(uint32_t)));
             HIPCHK(c->open_far.ensure(ntiles * match_tile_positions(g) * sizeof(uint32_t)));
@@ -278,6 +284,27 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
         }
         LAUNCH(K_INDEX, launch_index(g.data, g.end, ix0, be, bs, mp.window, set, ib0, status, c->index_safe, iso_first,
                                      iso_bytes, c->stream));
+        const uint8_t *walk_chunk = nullptr;  // null: every chunk goes the one way
+        if (walk_some) {
+            HIPCHK(c->walk_chunk.ensure(c1 - c0));
+            LAUNCH(K_MISC, launch_chunk_probe(g, c0, c1, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
+                                              c->walk_chunk.as<uint8_t>(), c->stream));
+            walk_chunk = c->walk_chunk.as<uint8_t>();
+        }
+        if (full) {
+            if (two_level) {
+                LAUNCH(K_MATCH, launch_match(g, c0, c1, mp, rec_min, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
+                                             c->match.as<uint32_t>(), c->open_list.as<uint32_t>(),
+                                             c->open_cnt.as<uint32_t>(), walk_chunk, c->stream));
+                LAUNCH(K_MATCH_LO, launch_match_lo(g, c0, c1, mp, c->far4.as<uint16_t>(), c->next4.as<uint16_t>(),
+                                                   c->far3.as<uint16_t>(), c->next3.as<uint16_t>(), ib0,
+                                                   c->match.as<uint32_t>(), c->open_list.as<uint32_t>(),
+                                                   c->open_far.as<uint32_t>(), c->open_cnt.as<uint32_t>(), c->stream));
+            } else {
+                LAUNCH(K_MATCH, launch_match(g, c0, c1, mp, rec_min, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
+                                             c->match.as<uint32_t>(), nullptr, nullptr, walk_chunk, c->stream));
+            }
+        }
         if (walk) {
             const uint32_t tpr = walk_tiles_per_run(g, c1 - c0, (uint32_t)c->cus);
             const uint64_t runs = (uint64_t)(c1 - c0) * ((match_tiles_per_chunk(g) + tpr - 1) / tpr);
@@ -285,18 +312,8 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
             const uint16_t *f3 = need3 ? c->far3.as<uint16_t>() : c->far4.as<uint16_t>();  // unread without need3
             const uint16_t *n3 = need3 ? c->next3.as<uint16_t>() : c->next4.as<uint16_t>();
             LAUNCH(K_WALK, launch_walk(g, c0, c1, mp, c->far4.as<uint16_t>(), c->next4.as<uint16_t>(), f3, n3, ib0,
-                                       c->match.as<uint32_t>(), c->walk_exit.as<uint32_t>(), tpr, c->stream));
-        } else if (two_level) {
-            LAUNCH(K_MATCH, launch_match(g, c0, c1, mp, rec_min, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
-                                         c->match.as<uint32_t>(), c->open_list.as<uint32_t>(),
-                                         c->open_cnt.as<uint32_t>(), c->stream));
-            LAUNCH(K_MATCH_LO, launch_match_lo(g, c0, c1, mp, c->far4.as<uint16_t>(), c->next4.as<uint16_t>(),
-                                               c->far3.as<uint16_t>(), c->next3.as<uint16_t>(), ib0,
-                                               c->match.as<uint32_t>(), c->open_list.as<uint32_t>(),
-                                               c->open_far.as<uint32_t>(), c->open_cnt.as<uint32_t>(), c->stream));
-        } else {
-            LAUNCH(K_MATCH, launch_match(g, c0, c1, mp, rec_min, c->far.as<uint16_t>(), c->next.as<uint16_t>(), ib0,
-                                         c->match.as<uint32_t>(), nullptr, nullptr, c->stream));
+                                       c->match.as<uint32_t>(), c->walk_exit.as<uint32_t>(), tpr, walk_chunk,
+                                       c->stream));
         }
     }
     {
@@ -523,7 +540,7 @@ int zg_init(int device, zg_ctx **ctx) {
     if (!c) return ZG_ERR_NOMEM;
     c->device = device;
     if (const char *e = std::getenv("ZLIB_AMD_SAFE_INDEX")) c->index_safe = e[0] == '1';  // test hook
-    if (const char *e = std::getenv("ZLIB_AMD_WALK")) c->walk_off = e[0] != '1';
+    if (const char *e = std::getenv("ZLIB_AMD_WALK")) c->walk_mode = e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2);
     if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->cus <= 0)
         c->cus = 256;
     // this device's copy of the fixed scratch array (the current device is `device`)
@@ -548,7 +565,7 @@ void zg_destroy(zg_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf *bufs[] = {&c->walk_exit, &c->shard_buf, &c->far, &c->next, &c->far4, &c->next4, &c->far3, &c->next3, &c->open_list, &c->open_far, &c->open_cnt, &c->rec_len, &c->rec_off, &c->inf_off, &c->inf_len, &c->inf_status, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
+    DevBuf *bufs[] = {&c->walk_exit, &c->walk_chunk, &c->shard_buf, &c->far, &c->next, &c->far4, &c->next4, &c->far3, &c->next3, &c->open_list, &c->open_far, &c->open_cnt, &c->rec_len, &c->rec_off, &c->inf_off, &c->inf_len, &c->inf_status, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
                       &c->block_bits, &c->bit_off, &c->tile_bits, &c->adler_part, &c->scalars, &c->stage_in,
                       &c->stage_out, &c->misc, &c->flag, &c->sub_exit, &c->sub_exit2, &c->merged, &c->tile_cnt,
                       &c->adler_blk};

@@ -112,9 +112,10 @@ uint64_t index_lookback(uint32_t window);
 // level 1: lengths >= rec_min along the five-byte chains.  With open_list it also lists, per tile, the positions
 // it leaves without a length (tile position | distance of the candidate that ended the search << 16; a tile's
 // list starts at tile index * match_tile_positions(g), its length goes to open_cnt[tile index]).
+// walk_chunk (may be null): chunks c0 + i with walk_chunk[i] != 0 are left alone (k_walk searches them)
 hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, uint32_t rec_min,
                         const uint16_t *far, const uint16_t *next, uint64_t base, uint32_t *match,
-                        uint32_t *open_list, uint32_t *open_cnt, hipStream_t s);
+                        uint32_t *open_list, uint32_t *open_cnt, const uint8_t *walk_chunk, hipStream_t s);
 // level 2: lengths 3 and 4 for the listed positions, from the four-byte and the three-byte index
 hipError_t launch_match_lo(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *far4,
                            const uint16_t *next4, const uint16_t *far3, const uint16_t *next3, uint64_t base,
@@ -125,9 +126,18 @@ hipError_t launch_match_lo(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPa
 // words per run of tiles_per_run tiles.
 uint32_t walk_tiles_per_run(const ChunkGrid &g, uint32_t n_chunks, uint32_t cus);
 // far4 / next4: the four-byte index; far3 / next3: the three-byte index, read only when mp.min_len == 3.
+// walk_chunk (may be null: every chunk): only chunks c0 + i with walk_chunk[i] != 0 are searched.
 hipError_t launch_walk(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *far4,
                        const uint16_t *next4, const uint16_t *far3, const uint16_t *next3, uint64_t base,
-                       uint32_t *match, uint32_t *exit_bits, uint32_t tiles_per_run, hipStream_t s);
+                       uint32_t *match, uint32_t *exit_bits, uint32_t tiles_per_run, const uint8_t *walk_chunk,
+                       hipStream_t s);
+// Which way is cheaper for a chunk?  The full search pays for every member of every five-byte chain, the walk
+// for the positions of the parse only: walk_chunk[i] = 1 for chunks whose five-byte chains are long (the mean
+// length over 256 sampled positions, extrapolated from each chain's first eight members, exceeds a threshold)
+// -- structured data, where the positions inside long matches sit on dense chains and the parse never visits
+// them.
+hipError_t launch_chunk_probe(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint16_t *far5,
+                              const uint16_t *next5, uint64_t base, uint8_t *walk_chunk, hipStream_t s);
 // status: bit 2 is raised when the parse stands on a position whose match[] is kUnvisited
 hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint32_t *match, uint64_t base,
                         uint8_t *flag, uint64_t flag_bytes, uint32_t *sub_exit, uint32_t *sub_exit2, uint8_t *merged,

@@ -565,7 +565,8 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                                                           const uint16_t *__restrict__ next, uint64_t base,
                                                           uint32_t *__restrict__ match,
                                                           uint32_t *__restrict__ open_list,
-                                                          uint32_t *__restrict__ open_cnt) {
+                                                          uint32_t *__restrict__ open_cnt,
+                                                          const uint8_t *__restrict__ walk_chunk) {
     // one LDS image: bytes first (so that byte reads need no base add), links behind them
     __shared__ __attribute__((aligned(16))) uint8_t s_mem[G::data_lds + 2 * G::next_lds];
     __shared__ uint32_t s_counter;  // next unclaimed position of the tile
@@ -579,7 +580,8 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     const uint64_t cs = first + (uint64_t)chunk * chunk_bytes;
     const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, chunk);
     const uint64_t t0 = cs + (uint64_t)tile * G::tile;
-    if (t0 >= ce) {
+    // nothing to do past the chunk's end, nor in a chunk that is left to the search along the parse (k_walk)
+    if (t0 >= ce || (walk_chunk && walk_chunk[chunk - c0])) {
         if (emit_term && threadIdx.x == 0) open_cnt[bid] = 0;
         return;
     }
@@ -1177,18 +1179,18 @@ __global__ __launch_bounds__(G::lo_threads) void k_match_lo(const uint8_t *__res
 
 hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, uint32_t rec_min,
                         const uint16_t *far, const uint16_t *next, uint64_t base, uint32_t *match,
-                        uint32_t *open_list, uint32_t *open_cnt, hipStream_t s) {
+                        uint32_t *open_list, uint32_t *open_cnt, const uint8_t *walk_chunk, hipStream_t s) {
     if (c1 <= c0) return hipSuccess;
     const uint32_t tpc = match_tiles_per_chunk(g);
     const uint64_t nblocks = (uint64_t)(c1 - c0) * tpc;
     if (match_tile_positions(g) == kMatchRecordTile)
         hipLaunchKernelGGL(k_match<GeomRecord>, dim3((uint32_t)nblocks), dim3(GeomRecord::threads), 0, s, g.data,
                            g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, rec_min,
-                           open_list ? 1u : 0u, far, next, base, match, open_list, open_cnt);
+                           open_list ? 1u : 0u, far, next, base, match, open_list, open_cnt, walk_chunk);
     else
         hipLaunchKernelGGL(k_match<GeomStream>, dim3((uint32_t)nblocks), dim3(GeomStream::threads), 0, s, g.data,
                            g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, rec_min,
-                           open_list ? 1u : 0u, far, next, base, match, open_list, open_cnt);
+                           open_list ? 1u : 0u, far, next, base, match, open_list, open_cnt, walk_chunk);
     return hipGetLastError();
 }
 

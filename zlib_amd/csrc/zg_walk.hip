@@ -200,7 +200,8 @@ __global__ __launch_bounds__(G::threads) void k_walk(
     const uint32_t *__restrict__ clen, uint32_t isolated, uint32_t c0, uint32_t tiles_per_run, uint32_t runs_per_chunk,
     MatchParams mp, uint32_t rec_min, uint32_t lo3, const uint16_t *__restrict__ far4,
     const uint16_t *__restrict__ next4, const uint16_t *__restrict__ far3, const uint16_t *__restrict__ next3,
-    uint64_t base, uint32_t *match, uint32_t *__restrict__ exit_bits, uint32_t fix_mode, uint32_t gap_shift) {
+    uint64_t base, uint32_t *match, uint32_t *__restrict__ exit_bits, uint32_t fix_mode, uint32_t gap_shift,
+    const uint8_t *__restrict__ walk_chunk) {
     __shared__ __attribute__((aligned(16))) uint8_t s_mem[G::data_lds + 2 * G::next_lds];
     __shared__ uint32_t s_vis[G::tile / 32];       // positions of the tile some walker has stood on
     __shared__ uint32_t s_exit[kWalkExitWords];    // bit i: a walker left the tile for its position tn + i
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(G::threads) void k_walk(
     const uint32_t chunk = c0 + bid / runs_per_chunk;
     const uint32_t run = bid % runs_per_chunk;
     if (fix_mode && run == 0) return;  // a chunk's first run starts at the chunk's first byte: nothing unknown
+    if (walk_chunk && !walk_chunk[chunk - c0]) return;  // this chunk is searched in full by k_match
     const uint64_t cs = first + (uint64_t)chunk * chunk_bytes;
     const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, chunk);
     const uint32_t tiles_in_chunk = (uint32_t)((ce - cs + G::tile - 1) / G::tile);
@@ -700,9 +702,61 @@ uint32_t walk_tiles_per_run(const ChunkGrid &g, uint32_t n_chunks, uint32_t cus)
     return (uint32_t)r;
 }
 
+#ifndef ZG_PROBE_THRESHOLD
+#define ZG_PROBE_THRESHOLD 96
+#endif
+constexpr uint32_t kProbeSteps = 8;  // members of a sampled chain that are walked; the rest is extrapolated
+
+__global__ __launch_bounds__(256) void k_chunk_probe(uint64_t first, uint64_t end, uint64_t chunk_bytes,
+                                                      const uint32_t *__restrict__ clen, uint32_t c0,
+                                                      const uint16_t *__restrict__ far5,
+                                                      const uint16_t *__restrict__ next5, uint64_t base,
+                                                      uint8_t *__restrict__ walk_chunk, uint32_t threshold) {
+    __shared__ uint32_t s_sum[4];
+    const uint32_t ci = blockIdx.x, tid = threadIdx.x;
+    const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
+    const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
+    const uint64_t len = ce - cs;
+    uint32_t steps = 0;  // (estimated) members of the sampled position's chain inside its window
+    if (len >= 256) {
+        // 256 positions spread over the chunk, each moved by a pseudo-random amount inside its stretch: evenly
+        // spaced samples would all fall on the same field of fixed-size records
+        const uint64_t stretch = len / 256;
+        const uint64_t p = cs + stretch * tid + ((tid * 2654435761u) >> 8) % stretch;
+        const uint32_t fd = far5[p - base];
+        uint64_t s = p - fd;
+        while (fd != 0 && s < p && steps < kProbeSteps) {
+            steps++;
+            const uint32_t nx = next5[s - base];
+            if (nx == 0) break;
+            s += nx;
+        }
+        // a chain that goes on is taken to keep the spacing of its first members up to the position
+        if (steps == kProbeSteps && s < p) steps = (uint32_t)((uint64_t)fd * kProbeSteps / (s - (p - fd)));
+    }
+    for (int off = 32; off > 0; off >>= 1) steps += __shfl_down(steps, off);
+    if ((tid & 63) == 0) s_sum[tid >> 6] = steps;
+    __syncthreads();
+    if (tid == 0) walk_chunk[ci] = (s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]) > threshold * 256u ? 1 : 0;
+}
+
+hipError_t launch_chunk_probe(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint16_t *far5,
+                              const uint16_t *next5, uint64_t base, uint8_t *walk_chunk, hipStream_t s) {
+    if (c1 <= c0) return hipSuccess;
+    static const uint32_t threshold = [] {
+        const char *e = std::getenv("ZLIB_AMD_PROBE_THRESHOLD");  // tuning hook
+        const int v = e ? atoi(e) : 0;
+        return (uint32_t)(v > 0 ? v : ZG_PROBE_THRESHOLD);
+    }();
+    hipLaunchKernelGGL(k_chunk_probe, dim3(c1 - c0), dim3(256), 0, s, g.first, g.end, g.chunk_bytes, g.chunk_len, c0,
+                       far5, next5, base, walk_chunk, threshold);
+    return hipGetLastError();
+}
+
 hipError_t launch_walk(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams mp, const uint16_t *far4,
                        const uint16_t *next4, const uint16_t *far3, const uint16_t *next3, uint64_t base,
-                       uint32_t *match, uint32_t *exit_bits, uint32_t tiles_per_run, hipStream_t s) {
+                       uint32_t *match, uint32_t *exit_bits, uint32_t tiles_per_run, const uint8_t *walk_chunk,
+                       hipStream_t s) {
     if (c1 <= c0) return hipSuccess;
     const uint32_t tpc = match_tiles_per_chunk(g);
     const uint32_t rpc = (tpc + tiles_per_run - 1) / tiles_per_run;
@@ -718,7 +772,7 @@ hipError_t launch_walk(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams
         if (mode == 1 && rpc == 1) break;  // every run starts a chunk
         hipLaunchKernelGGL(k_walk<GeomStream>, dim3((uint32_t)nblocks), dim3(GeomStream::threads), 0, s, g.data, g.first,
                            g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tiles_per_run, rpc, mp, rec_min, lo3, far4,
-                           next4, far3, next3, base, match, exit_bits, mode, gap_shift);
+                           next4, far3, next3, base, match, exit_bits, mode, gap_shift, walk_chunk);
     }
     return hipGetLastError();
 }
