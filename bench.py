@@ -120,15 +120,23 @@ def verify_stream(za, stream, kind, seed, total):
     return pos + len(tail) == total and not tail and d.eof and not d.unused_data
 
 
-def measured_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel`, as collected with tools/collect_profiles.sh (counters cannot be read from
-    inside the timed process); None when the committed profile has no entry for this workload."""
+TRAFFIC_FILE = "r2_traffic.json"
+
+
+def measured_traffic(workload, kernel, live_avg_ms):
+    """(HBM bytes per launch of `kernel`, stale?) as collected with tools/collect_profiles.sh -- counters cannot be
+    read from inside the timed process.  The profile also holds the kernel's mean duration in its own run: when
+    this run's differs by more than a fifth, the kernel has changed since and the figure is marked stale.
+    (None, None) when the committed profile has no entry for this workload and kernel."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
             t = json.load(f)["workloads"]
-        return t[workload][kernel]["hbm_bytes_per_launch"]
+        e = t[workload][kernel if kernel in t[workload] else kernel + "_r"]
+        then = e.get("avg_ms_in_stats_run")
+        stale = None if not then else abs(live_avg_ms / then - 1.0) > 0.2
+        return e["hbm_bytes_per_launch"], stale
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def cpu_baseline(za, kind, seed, total, chunk, torch=None, ctx=None, device=None):
@@ -299,7 +307,7 @@ def main():
         launches_per_step = kn / args.steps
         bytes_per_launch = n * (1.0 + ratio) / max(1.0, launches_per_step)  # this rank's share
         achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9
-        traffic = measured_traffic(args.workload, kname) if world == 1 else None
+        traffic, traffic_stale = measured_traffic(args.workload, kname, k_avg_ms) if world == 1 else (None, None)
         line = {
             "metric": f"compress input GB/s ({strat_name})", "value": value, "unit": "GB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -315,10 +323,11 @@ def main():
                                        "chunks sharded over ranks; all_gather of bit totals + payload send to rank 0")
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale,
                          "traffic_note": "HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (separate rocprofv3 --pmc "
-                                         "passes over this command, profiles/r1_traffic.json); null if not collected "
-                                         "for this workload",
+                                         f"passes over this command, profiles/{TRAFFIC_FILE}); null if not collected "
+                                         "for this workload; stale: the kernel's duration has moved by more than a "
+                                         "fifth since the counters were taken",
                          "kernel_avg_ms": k_avg_ms, "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "algorithmic bytes = input bytes read once + compressed bytes written once"},

@@ -46,13 +46,34 @@ for d in sorted(glob.glob(f"{src}/fetch_*")):
         t[k] = {"launches": n, "fetch_size_kb_per_launch": fetch_kb, "write_size_kb_per_launch": write_kb,
                 "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024}
     traffic[wl] = t
+for wl, t in traffic.items():  # mean kernel durations of the same workload, for a check against a later run
+    f = one(f"{src}/stats_{wl}/**/*kernel_stats.csv")
+    if not f:
+        continue
+    for r in csv.DictReader(open(f)):
+        k = kname(r["Name"])
+        if k in t:
+            t[k]["avg_ms_in_stats_run"] = float(r["AverageNs"]) / 1e6
 json.dump({"note": "per launch, one bench step; hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (FETCH_SIZE counts wide reads at half "
                    "their size on gfx950); separate rocprofv3 --pmc passes", "workloads": traffic},
           open(f"profiles/{tag}_traffic.json", "w"), indent=1)
-sa, _ = pmc(f"{src}/sqa_text64m")
-sb, _ = pmc(f"{src}/sqb_text64m")
-with open(f"profiles/{tag}_text64m_sq_counters.txt", "w") as o:
-    for k in sorted(set(sa) | set(sb)):
-        v = {**sa.get(k, {}), **sb.get(k, {})}
-        o.write(k + " " + json.dumps({a: float(f"{b:.4g}") for a, b in sorted(v.items())}) + "\n")
+for wl in ("mixed8g", "text64m"):
+    if not os.path.isdir(f"{src}/sqa_{wl}"):
+        continue
+    sa, _ = pmc(f"{src}/sqa_{wl}")
+    sb, _ = pmc(f"{src}/sqb_{wl}")
+    with open(f"profiles/{tag}_{wl}_sq_counters.txt", "w") as o:
+        for k in sorted(set(sa) | set(sb)):
+            v = {**sa.get(k, {}), **sb.get(k, {})}
+            if v.get("SQ_LDS_IDX_ACTIVE"):
+                v["lds_conflict_frac"] = v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"]
+            o.write(k + " " + json.dumps({a: float(f"{b:.4g}") for a, b in sorted(v.items())}) + "\n")
+# the bench lines themselves, one file per workload, and the kernels' mean durations beside the traffic figures
+for f in sorted(glob.glob(f"{src}/bench_*.json")):
+    wl = os.path.basename(f)[len("bench_"):-len(".json")]
+    try:
+        line = json.loads(open(f).read().strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        continue
+    json.dump(line, open(f"profiles/{tag}_bench_{wl}.json", "w"), indent=1)
 print(open(f"profiles/{tag}_traffic.json").read()[:3000])

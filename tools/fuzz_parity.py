@@ -61,9 +61,9 @@ def first_diff(a, b):
     return next((k for k in range(m) if a[k] != b[k]), m)
 
 
-def run(budget, seed, max_cases=None):
+def run(budget, seed, max_cases=None, ctx=None):
     """Runs cases for `budget` seconds, or exactly `max_cases` cases when that is given (the same cases on every
-    machine); (all equal, number of cases)."""
+    machine), on context `ctx` (None: the default one); (all equal, number of cases)."""
     global rng
     rng = random.Random(seed)
     t_end = time.time() + budget
@@ -77,7 +77,7 @@ def run(budget, seed, max_cases=None):
         data = gen(n) if n else b""
         mode = rng.randrange(6)
         if mode == 0:  # units, zlib parameters
-            got, want = za.zlib_compressor().compress_packed(data), z.lz77_zlib(data, fast=True)
+            got, want = za.zlib_compressor().compress_packed(data, ctx=ctx), z.lz77_zlib(data, fast=True)
             what = "lz77 zlib"
         elif mode == 1:  # units, other parameters (against the verbatim loop: keep the input short)
             data = data[:12_000]
@@ -87,19 +87,19 @@ def run(budget, seed, max_cases=None):
             mx = max(mx, mn + 1)
             comp = za.LZ77Compressor.with_window_size(w)
             comp.min_match_length, comp.max_match_length = mn, mx
-            got, want = comp.compress_packed(data), z.lz77_compress(data, 0, w, mn, mx)
+            got, want = comp.compress_packed(data, ctx=ctx), z.lz77_compress(data, 0, w, mn, mx)
             what = f"lz77 w={w} min={mn} max={mx}"
         elif mode == 2:  # streams, several chunks
             chunk = rng.choice([1024, 4096, 16384, 65536, 1 << 20])
             strat = rng.choice([za.Strategy.Dynamic, za.Strategy.Fixed])
-            got = za.compress(data, strat, chunk_bytes=chunk)
+            got = za.compress(data, strat, chunk_bytes=chunk, ctx=ctx)
             want = z.compress_chunked(data, z.DYNAMIC if strat == za.Strategy.Dynamic else z.FIXED, chunk, fast=True)
             what = f"stream chunk={chunk} {strat}"
             assert zlib.decompress(got) == data
         elif mode == 4:  # streams cut into several batches (scratch arrays restart a window behind each batch)
             chunk = rng.choice([1024, 4096, 16384, 65536])
             batch = chunk * rng.randint(1, 4)
-            got = za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk, batch_bytes=batch)
+            got = za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk, batch_bytes=batch, ctx=ctx)
             want = z.compress_chunked(data, z.DYNAMIC, chunk, fast=True)
             what = f"stream chunk={chunk} batch={batch}"
         elif mode == 5:  # a few large records: isolated slots longer than the window
@@ -108,7 +108,7 @@ def run(budget, seed, max_cases=None):
                 m = rng.choice([30_000, 40_000, 70_000, 100_000])
                 recs.append(data[pos:pos + m])
                 pos += m
-            got = b"".join(za.compress_batch(recs, za.Strategy.Dynamic)) if recs else b""
+            got = b"".join(za.compress_batch(recs, za.Strategy.Dynamic, ctx=ctx)) if recs else b""
             want = b"".join(z.compress_chunked(r, z.DYNAMIC, 1 << 20, fast=True) for r in recs)
             what = f"batch of {len(recs)} large records"
         else:  # record batch
@@ -117,7 +117,7 @@ def run(budget, seed, max_cases=None):
                 m = rng.choice([1, 7, 100, 1000, 4096, 5000])
                 recs.append(data[pos:pos + m])
                 pos += m
-            got_l = za.compress_batch(recs, za.Strategy.Dynamic) if recs else []
+            got_l = za.compress_batch(recs, za.Strategy.Dynamic, ctx=ctx) if recs else []
             got = b"".join(got_l)
             want = b"".join(z.compress_chunked(r, z.DYNAMIC, 1 << 20, fast=True) for r in recs)
             what = f"batch of {len(recs)} records"

@@ -766,7 +766,7 @@ hipError_t launch_walk(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParams
     static const uint32_t gap_shift = [] {
         const char *e = std::getenv("ZLIB_AMD_WALK_GAP_SHIFT");  // tuning hook: walkers start every 2^shift positions
         const int v = e ? atoi(e) : 0;
-        return (uint32_t)((v >= 3 && v <= 14) ? v : 4);
+        return (uint32_t)((v >= 1 && v <= 14) ? v : 4);
     }();
     for (uint32_t mode = 0; mode < 2; mode++) {
         if (mode == 1 && rpc == 1) break;  // every run starts a chunk
