@@ -8,6 +8,10 @@ pub struct ZgOpts {
 }
 
 pub const ZG_ERR_DATA: c_int = -8;
+pub const ZG_ERR_IO: c_int = -9;
+
+pub type ZgReadFn = unsafe extern "C" fn(user: *mut c_void, buf: *mut u8, cap: usize) -> usize;
+pub type ZgWriteFn = unsafe extern "C" fn(user: *mut c_void, buf: *const u8, n: usize) -> c_int;
 
 extern "C" {
     pub fn zg_strerror(code: c_int) -> *const c_char;
@@ -17,6 +21,11 @@ extern "C" {
                        out: *mut *mut u8, out_n: *mut usize) -> c_int;
     pub fn zg_compress_multi(devices: *const c_int, n_devices: c_int, input: *const u8, n: usize, strategy: c_int,
                              opts: *const ZgOpts, out: *mut *mut u8, out_n: *mut usize) -> c_int;
+    pub fn zg_compress_stream(ctx: *mut c_void, read_fn: ZgReadFn, read_user: *mut c_void, write_fn: ZgWriteFn,
+                              write_user: *mut c_void, strategy: c_int, opts: *const ZgOpts, size_hint: u64,
+                              in_total: *mut u64, out_total: *mut u64) -> c_int;
+    pub fn zg_compress_file(ctx: *mut c_void, in_path: *const c_char, out_path: *const c_char, strategy: c_int,
+                            opts: *const ZgOpts, in_bytes: *mut u64, out_bytes: *mut u64) -> c_int;
     pub fn zg_compress_batch(ctx: *mut c_void, input: *const u8, offsets: *const usize, n_records: usize,
                              strategy: c_int, out: *mut *mut u8, out_offsets: *mut *mut usize) -> c_int;
     pub fn zg_decompress(ctx: *mut c_void, input: *const u8, n: usize, out: *mut *mut u8, out_n: *mut usize) -> c_int;

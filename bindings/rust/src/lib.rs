@@ -61,6 +61,73 @@ pub mod compress {
         unsafe { take(out, n) }
     }
 
+    /// New item: compress from any `Read` into any `Write` without holding the whole input in memory; the bytes
+    /// written are those `compress` returns for the whole input.  Returns (input bytes, stream bytes).
+    pub fn compress_stream<R: std::io::Read + Send, W: std::io::Write + Send>(
+        reader: &mut R, writer: &mut W, strategy: &Strategy,
+    ) -> std::io::Result<(u64, u64)> {
+        use std::os::raw::{c_int, c_void};
+        // One end per callback: the library calls `pull` from one of its threads and `push` from another, each
+        // from that thread only and never after zg_compress_stream has returned, so the two never share state.
+        struct End<'a, T> {
+            io: &'a mut T,
+            err: Option<std::io::Error>,
+        }
+        unsafe extern "C" fn pull<R: std::io::Read>(user: *mut c_void, buf: *mut u8, cap: usize) -> usize {
+            let end = &mut *(user as *mut End<R>);
+            loop {
+                match end.io.read(std::slice::from_raw_parts_mut(buf, cap)) {
+                    Ok(n) => return n,
+                    Err(e) if e.kind() == std::io::ErrorKind::Interrupted => continue,
+                    Err(e) => {
+                        end.err = Some(e);
+                        return usize::MAX;
+                    }
+                }
+            }
+        }
+        unsafe extern "C" fn push<W: std::io::Write>(user: *mut c_void, buf: *const u8, n: usize) -> c_int {
+            let end = &mut *(user as *mut End<W>);
+            match end.io.write_all(std::slice::from_raw_parts(buf, n)) {
+                Ok(()) => 0,
+                Err(e) => {
+                    end.err = Some(e);
+                    -1
+                }
+            }
+        }
+        let mut src = End { io: reader, err: None };
+        let mut dst = End { io: writer, err: None };
+        let (mut n_in, mut n_out) = (0u64, 0u64);
+        let rc = unsafe {
+            ffi::zg_compress_stream(std::ptr::null_mut(), pull::<R>, &mut src as *mut End<R> as *mut c_void, push::<W>,
+                                    &mut dst as *mut End<W> as *mut c_void, code(strategy), std::ptr::null(), 0,
+                                    &mut n_in, &mut n_out)
+        };
+        if let Some(e) = src.err.take().or(dst.err.take()) {
+            return Err(e);
+        }
+        check(rc);
+        Ok((n_in, n_out))
+    }
+
+    /// New item: `compress_stream` between two paths, read and written by the library itself.
+    pub fn compress_file(input: &std::path::Path, output: &std::path::Path, strategy: &Strategy) -> std::io::Result<(u64, u64)> {
+        use std::os::unix::ffi::OsStrExt;
+        let a = std::ffi::CString::new(input.as_os_str().as_bytes())?;
+        let b = std::ffi::CString::new(output.as_os_str().as_bytes())?;
+        let (mut n_in, mut n_out) = (0u64, 0u64);
+        let rc = unsafe {
+            ffi::zg_compress_file(std::ptr::null_mut(), a.as_ptr(), b.as_ptr(), code(strategy), std::ptr::null(), &mut n_in, &mut n_out)
+        };
+        if rc == ffi::ZG_ERR_IO {
+            let msg = unsafe { std::ffi::CStr::from_ptr(ffi::zg_last_error(std::ptr::null_mut())) }.to_string_lossy().into_owned();
+            return Err(std::io::Error::new(std::io::ErrorKind::Other, msg));
+        }
+        check(rc);
+        Ok((n_in, n_out))
+    }
+
     /// New item: every record compressed as a zlib stream of its own, all in flight together.
     pub fn compress_many(records: &[&[u8]], strategy: &Strategy) -> Vec<Vec<u8>> {
         if !matches!(strategy, Strategy::Dynamic | Strategy::Fixed) {

@@ -76,3 +76,19 @@ fn test_units_and_trees_equal_the_crates_own() {
     assert_eq!(lt.encodings().unwrap().len(), lo.encodings().unwrap().len());
     assert_eq!(dt.encodings().unwrap().len(), d_o.encodings().unwrap().len());
 }
+
+#[test]
+fn test_stream_front_end_gives_the_bytes_of_compress() {
+    // new items of the shim: the same stream from a Read into a Write, and between two paths
+    let data = words(7, 3 << 20);
+    let want = compress(&data, &Strategy::Dynamic);
+    let mut got = Vec::new();
+    let (n_in, n_out) = zlib_amd_shim::compress::compress_stream(&mut &data[..], &mut got, &Strategy::Dynamic).unwrap();
+    assert_eq!((n_in as usize, n_out as usize), (data.len(), got.len()));
+    assert_eq!(got, want);
+    let dir = std::env::temp_dir();
+    let (src, dst) = (dir.join("zlib_amd_stream_in.bin"), dir.join("zlib_amd_stream_out.z"));
+    std::fs::write(&src, &data).unwrap();
+    zlib_amd_shim::compress::compress_file(&src, &dst, &Strategy::Dynamic).unwrap();
+    assert_eq!(std::fs::read(&dst).unwrap(), want);
+}

@@ -38,7 +38,8 @@ enum {
     ZG_ERR_CAPACITY = -5,    /* caller-provided output buffer too small               */
     ZG_ERR_UNSUPPORTED = -6, /* parameters outside what the device path implements    */
     ZG_ERR_INTERNAL = -7,    /* a device-side consistency check failed                */
-    ZG_ERR_DATA = -8         /* decompress: invalid or corrupt zlib stream            */
+    ZG_ERR_DATA = -8,        /* decompress: invalid or corrupt zlib stream            */
+    ZG_ERR_IO = -9           /* stream / file front end: a read or write failed       */
 };
 
 /* Strategy: src/compress.rs:28-34 (same order). */
@@ -96,6 +97,31 @@ int zg_compress_device(zg_ctx *ctx, const void *d_in, size_t n, int strategy, co
  * (zg_free).  Calls are serialised by a lock of their own. */
 int zg_compress_multi(const int *devices, int n_devices, const uint8_t *in, size_t n, int strategy,
                       const zg_opts *opts, uint8_t **out, size_t *out_n);
+
+/* The same call for input that is not in memory as a whole (a file, a pipe, a
+ * socket): zlib::compress (src/compress.rs:51-86) takes a slice, so a caller of
+ * the reference has to load everything first; here the input is pulled through
+ * read_fn segment by segment (a whole number of chunks, batch_bytes by default)
+ * and the stream is pushed through write_fn as it is finished, while the next
+ * segment is being read and uploaded and the previous one downloaded.  The
+ * bytes handed to write_fn, in order, are byte for byte what zg_compress
+ * returns for the whole input with the same strategy and options.
+ *   read_fn(user, buf, cap): put up to cap bytes into buf and return their
+ *     number; 0 = end of input; (size_t)-1 = failure (ZG_ERR_IO).
+ *   write_fn(user, buf, n): take n bytes; non-zero = failure (ZG_ERR_IO).
+ * Both are called from threads of the library, never at the same time as
+ * themselves.  size_hint: the input's length if known (only sizes the
+ * buffers; 0 = unknown).  *in_total / *out_total (may be NULL) receive the byte
+ * counts.  With chunk_bytes not a multiple of 16 KiB a segment is
+ * chunk_bytes * 16 KiB / gcd of the two; above 1 GiB: ZG_ERR_UNSUPPORTED.
+ * zg_compress_file does the same between two paths. */
+typedef size_t (*zg_read_fn)(void *user, uint8_t *buf, size_t cap);
+typedef int (*zg_write_fn)(void *user, const uint8_t *buf, size_t n);
+int zg_compress_stream(zg_ctx *ctx, zg_read_fn read_fn, void *read_user, zg_write_fn write_fn,
+                       void *write_user, int strategy, const zg_opts *opts, uint64_t size_hint,
+                       uint64_t *in_total, uint64_t *out_total);
+int zg_compress_file(zg_ctx *ctx, const char *in_path, const char *out_path, int strategy,
+                     const zg_opts *opts, uint64_t *in_bytes, uint64_t *out_bytes);
 
 /* Where the blocks of the last zg_compress, zg_compress_device (Dynamic / Fixed)
  * or zg_shard_begin call on this ctx start: bit_offsets[i] receives the bit

@@ -13,12 +13,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzlib_amd.so")
 
 OK = 0
-ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_INTERNAL, ERR_DATA = -1, -2, -3, -4, -5, -6, -7, -8
+ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_INTERNAL, ERR_DATA, ERR_IO = -1, -2, -3, -4, -5, -6, -7, -8, -9
 
 #: every symbol include/zlib_amd.h declares
 SYMBOLS = [
     "zg_init", "zg_destroy", "zg_strerror", "zg_last_error", "zg_free", "zg_compress", "zg_compress_bound",
-    "zg_compress_device", "zg_compress_multi", "zg_last_block_offsets", "zg_compress_batch", "zg_compress_batch_bound", "zg_compress_batch_device",
+    "zg_compress_device", "zg_compress_multi", "zg_compress_stream", "zg_compress_file", "zg_last_block_offsets", "zg_compress_batch", "zg_compress_batch_bound", "zg_compress_batch_device",
     "zg_decompress", "zg_decompress_batch", "zg_decompress_batch_device", "zg_shard_begin", "zg_shard_finish", "zg_adler32_combine", "zg_adler32",
     "zg_adler32_device", "zg_adler32_device_noalloc", "zg_lz77", "zg_huffman_from_tokens", "zg_profile_enable", "zg_profile_reset",
     "zg_profile_count", "zg_profile_get", "zg_corpus_fill",
@@ -31,6 +31,11 @@ class Opts(C.Structure):
 
 class ShardInfo(C.Structure):
     _fields_ = [("total_bits", C.c_uint64), ("adler", C.c_uint32), ("n_chunks", C.c_uint32)]
+
+
+#: size_t read_fn(void *user, uint8_t *buf, size_t cap) / int write_fn(void *user, const uint8_t *buf, size_t n)
+READ_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
 
 
 class ZgError(RuntimeError):
@@ -74,6 +79,10 @@ def _declare(L):
     f("zg_compress_device", C.c_int, vp, vp, sz, C.c_int, C.POINTER(Opts), vp, sz, C.POINTER(sz))
     f("zg_compress_multi", C.c_int, C.POINTER(C.c_int), C.c_int, C.c_char_p, sz, C.c_int, C.POINTER(Opts),
       C.POINTER(u8p), C.POINTER(sz))
+    f("zg_compress_stream", C.c_int, vp, READ_FN, vp, WRITE_FN, vp, C.c_int, C.POINTER(Opts), C.c_uint64,
+      C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+    f("zg_compress_file", C.c_int, vp, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(Opts), C.POINTER(C.c_uint64),
+      C.POINTER(C.c_uint64))
     f("zg_last_block_offsets", sz, vp, C.POINTER(C.c_uint64), sz)
     f("zg_compress_batch", C.c_int, vp, C.c_char_p, C.POINTER(sz), sz, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
       C.POINTER(C.POINTER(sz)))

@@ -93,7 +93,7 @@ def default_context() -> Context:
 def _check(rc: int, ctx: Optional[Context] = None):
     if rc:
         detail = ""
-        if rc in (_lib.ERR_HIP, _lib.ERR_DATA, _lib.ERR_CAPACITY) and ctx is not None:
+        if rc in (_lib.ERR_HIP, _lib.ERR_DATA, _lib.ERR_CAPACITY, _lib.ERR_IO) and ctx is not None:
             detail = _lib.lib().zg_last_error(ctx.handle).decode()
         raise ZgError(rc, detail)
 
@@ -145,6 +145,59 @@ def compress_multi(data: bytes, devices: Sequence[int], strategy: Strategy = Str
         return C.string_at(out, n.value)
     finally:
         _lib.lib().zg_free(out)
+
+
+def compress_stream(reader, writer, strategy: Strategy = Strategy.Dynamic, *, chunk_bytes: int = 0,
+                    batch_bytes: int = 0, size_hint: int = 0, ctx: Optional[Context] = None) -> Tuple[int, int]:
+    """zlib::compress for input that is not in memory as a whole: `reader.readinto(buffer)` (or `.read(n)`)
+    delivers the input, `writer.write(bytes)` receives the stream, a segment of `batch_bytes` at a time while the
+    neighbouring segments are read, uploaded and downloaded.  Returns (input bytes, stream bytes); the bytes
+    written are those compress() returns for the whole input."""
+    ctx = ctx or default_context()
+    failure: List[BaseException] = []
+
+    def _read(_user, buf, cap):
+        try:
+            if hasattr(reader, "readinto"):
+                view = (C.c_uint8 * cap).from_address(C.addressof(buf.contents))
+                got = reader.readinto(memoryview(view).cast("B"))
+                return int(got or 0)
+            chunk = reader.read(cap)
+            C.memmove(buf, chunk, len(chunk))
+            return len(chunk)
+        except BaseException as e:  # an exception must not cross the C frames: report a failed read
+            failure.append(e)
+            return C.c_size_t(-1).value
+
+    def _write(_user, buf, n):
+        try:
+            writer.write(C.string_at(buf, n))
+            return 0
+        except BaseException as e:
+            failure.append(e)
+            return -1
+
+    rfn, wfn = _lib.READ_FN(_read), _lib.WRITE_FN(_write)
+    o = _opts(chunk_bytes, batch_bytes)
+    n_in, n_out = C.c_uint64(), C.c_uint64()
+    rc = _lib.lib().zg_compress_stream(ctx.handle, rfn, None, wfn, None, int(strategy), C.byref(o), size_hint,
+                                       C.byref(n_in), C.byref(n_out))
+    if failure:
+        raise failure[0]
+    _check(rc, ctx)
+    return n_in.value, n_out.value
+
+
+def compress_file(in_path: str, out_path: str, strategy: Strategy = Strategy.Dynamic, *, chunk_bytes: int = 0,
+                  batch_bytes: int = 0, ctx: Optional[Context] = None) -> Tuple[int, int]:
+    """compress_stream between two paths (read and written by the library itself)."""
+    ctx = ctx or default_context()
+    o = _opts(chunk_bytes, batch_bytes)
+    n_in, n_out = C.c_uint64(), C.c_uint64()
+    import os
+    _check(_lib.lib().zg_compress_file(ctx.handle, os.fsencode(in_path), os.fsencode(out_path), int(strategy),
+                                       C.byref(o), C.byref(n_in), C.byref(n_out)), ctx)
+    return n_in.value, n_out.value
 
 
 def last_block_offsets(*, ctx: Optional[Context] = None) -> List[int]:

@@ -2,10 +2,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -586,6 +588,7 @@ const char *zg_strerror(int code) {
     case ZG_ERR_UNSUPPORTED: return "parameters not supported by the device path";
     case ZG_ERR_INTERNAL: return "internal consistency check failed";
     case ZG_ERR_DATA: return "invalid or corrupt zlib stream";
+    case ZG_ERR_IO: return "a read or write of the stream front end failed";
     default: return "unknown error";
     }
 }
@@ -1127,17 +1130,17 @@ int zg_huffman_from_tokens(zg_ctx *ctx, const uint32_t *tokens, size_t n, uint8_
     return ZG_OK;
 }
 
-int zg_shard_begin(zg_ctx *ctx, const void *d_in, size_t halo, size_t n, int strategy, const zg_opts *opts,
-                   int last_rank, zg_shard_info *info) {
-    int rc = 0;
-    zg_ctx *c = resolve(ctx, &rc);
-    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+}  // extern "C"
+
+namespace {
+// zg_shard_begin with the context's lock held by the caller
+int shard_begin_locked(zg_ctx *c, const void *d_in, size_t halo, size_t n, int strategy, const zg_opts *opts,
+                       int last_rank, zg_shard_info *info) {
     if (!info || (!d_in && (n || halo)) || halo > kMaxWindow) return ZG_ERR_ARG;
     if (strategy != ZG_DYNAMIC && strategy != ZG_FIXED) return ZG_ERR_UNSUPPORTED;
     Plan plan;
-    rc = make_plan(opts, &plan);
+    int rc = make_plan(opts, &plan);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
     c->shard_active = false;
     ChunkGrid g;
@@ -1198,7 +1201,6 @@ int zg_shard_begin(zg_ctx *ctx, const void *d_in, size_t halo, size_t n, int str
     }
 }
 
-namespace {
 // out = in shifted up by s bits (0 <= s <= 16), as 32-bit little-endian words
 __global__ __launch_bounds__(256) void k_shift_bits(const uint32_t *__restrict__ in, uint64_t n_in,
                                                      uint32_t *__restrict__ out, uint64_t n_out, uint32_t s) {
@@ -1208,15 +1210,11 @@ __global__ __launch_bounds__(256) void k_shift_bits(const uint32_t *__restrict__
     const uint32_t lo = (j >= 1 && j - 1 < n_in) ? in[j - 1] : 0u;
     out[j] = s ? (hi << s) | (lo >> (32 - s)) : hi;
 }
-}  // namespace
 
-int zg_shard_finish(zg_ctx *ctx, uint64_t base_bit, int first_rank, int last_rank, uint32_t adler, void *d_out,
-                    size_t out_cap, size_t *out_bytes) {
-    int rc = 0;
-    zg_ctx *c = resolve(ctx, &rc);
-    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+// zg_shard_finish with the context's lock held by the caller
+int shard_finish_locked(zg_ctx *c, uint64_t base_bit, int first_rank, int last_rank, uint32_t adler, void *d_out,
+                        size_t out_cap, size_t *out_bytes) {
     if (!d_out || !out_bytes || (reinterpret_cast<uintptr_t>(d_out) & 3)) return ZG_ERR_ARG;
-    std::lock_guard<std::mutex> lk(c->mu);
     if (!c->shard_active) return ZG_ERR_ARG;
     if (first_rank && base_bit != 16) return ZG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
@@ -1245,6 +1243,27 @@ int zg_shard_finish(zg_ctx *ctx, uint64_t base_bit, int first_rank, int last_ran
     if (h.status & 1u) return ZG_ERR_CAPACITY;
     *out_bytes = (size_t)h.out_bytes;
     return ZG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int zg_shard_begin(zg_ctx *ctx, const void *d_in, size_t halo, size_t n, int strategy, const zg_opts *opts,
+                   int last_rank, zg_shard_info *info) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return shard_begin_locked(c, d_in, halo, n, strategy, opts, last_rank, info);
+}
+
+int zg_shard_finish(zg_ctx *ctx, uint64_t base_bit, int first_rank, int last_rank, uint32_t adler, void *d_out,
+                    size_t out_cap, size_t *out_bytes) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return shard_finish_locked(c, base_bit, first_rank, last_rank, adler, d_out, out_cap, out_bytes);
 }
 
 // ---------------------------------------------------------------------------
@@ -1383,6 +1402,354 @@ int zg_compress_multi(const int *devices, int n_devices, const uint8_t *in, size
     *out = h;
     *out_n = total;
     return ZG_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// zg_compress_stream / zg_compress_file: the input arrives through a callback and the stream leaves through
+// another, a segment (a whole number of chunks, one pass over the scratch buffers by default) at a time.  Three
+// threads work on neighbouring segments: one reads segment k + 1 into pinned memory and uploads it, this one
+// compresses segment k (zg_shard_begin / zg_shard_finish on the segment and the 32 KiB before it), one downloads
+// and hands on segment k - 1.  Two neighbouring segments share at most one byte of the stream; it is held back
+// until the second one has arrived.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct StreamIn {  // one of two input slots
+    uint8_t *h = nullptr;  // pinned: halo + segment
+    void *d = nullptr;
+    size_t halo = 0, n = 0;
+    bool last = false;
+};
+struct StreamOut {  // one of two output slots and what the writer is to do with it
+    DevBuf d;
+    uint8_t *h = nullptr;  // pinned, grown on demand by the writer
+    size_t h_cap = 0;
+    size_t off = 0, len = 0;       // bytes [off, off + len) of d belong to the stream
+    bool or_first = false;         // the first of them shares its byte with the byte held back
+    bool hold_last = false;        // the last of them is not complete yet
+    int64_t clear_at = -1;         // stored blocks: header byte whose BFINAL bit does not belong to the stream
+    uint8_t tail[4] = {0, 0, 0, 0};
+    size_t tail_n = 0;             // bytes appended behind them (Adler-32 of a stream of stored blocks)
+    bool last = false;
+};
+
+struct StreamPipe {
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t filled = 0, consumed = 0, packed = 0, written = 0;
+    int rc = ZG_OK;  // first failure of any of the three threads
+    std::string what;
+    void fail(int code, const char *msg) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!rc) {
+            rc = code;
+            what = msg;
+        }
+        cv.notify_all();
+    }
+    template <class F> bool wait(F &&ready) {  // false: another thread has failed
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return rc != ZG_OK || ready(); });
+        return rc == ZG_OK;
+    }
+    template <class F> void post(F &&change) {
+        std::lock_guard<std::mutex> lk(mu);
+        change();
+        cv.notify_all();
+    }
+};
+
+size_t gcd_sz(size_t a, size_t b) {
+    while (b) {
+        const size_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+int compress_stream_locked(zg_ctx *c, zg_read_fn read_fn, void *read_user, zg_write_fn write_fn, void *write_user,
+                           int strategy, const zg_opts *opts, uint64_t size_hint, uint64_t *in_total,
+                           uint64_t *out_total) {
+    Plan plan;
+    int rc = make_plan(opts, &plan);
+    if (rc) return rc;
+    if (strategy < ZG_AUTO || strategy > ZG_RAW) return ZG_ERR_ARG;
+    // A segment is a whole number of chunks and of 16 KiB stored blocks, so that the blocks of the stream are the
+    // blocks of a call on the whole input whatever the strategy turns out to be.
+    const size_t unit = plan.chunk_bytes / gcd_sz(plan.chunk_bytes, kStoredBlock) * kStoredBlock;
+    if (unit > ((size_t)1 << 30)) return ZG_ERR_UNSUPPORTED;
+    size_t seg = std::max<size_t>(1, plan.batch_chunks * plan.chunk_bytes / unit) * unit;
+    if (size_hint && size_hint < seg) seg = (size_t)((size_hint + unit) / unit) * unit;  // room for the hint + 1 byte
+    const size_t halo_max = std::min<size_t>(kMaxWindow, seg);
+    HIPCHK(hipSetDevice(c->device));
+
+    StreamIn in[2];
+    StreamOut out[2];
+    StreamPipe pipe;
+    hipStream_t rs = nullptr, ws = nullptr;
+    auto release = [&] {
+        for (auto &s : in) {
+            if (s.h) (void)hipHostFree(s.h);
+            if (s.d) (void)hipFree(s.d);
+        }
+        for (auto &s : out) {
+            if (s.h) (void)hipHostFree(s.h);
+            s.d.release();
+        }
+        if (rs) (void)hipStreamDestroy(rs);
+        if (ws) (void)hipStreamDestroy(ws);
+    };
+    hipError_t e = hipStreamCreateWithFlags(&rs, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ws, hipStreamNonBlocking);
+    for (auto &s : in) {
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h), halo_max + seg, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(&s.d, halo_max + seg + 64);
+    }
+    if (e != hipSuccess) {
+        release();
+        return fail_hip(c, e, "buffers of zg_compress_stream");
+    }
+
+    uint64_t n_in = 0, n_out = 0;
+    const int device = c->device;
+
+    auto reader = [&] {
+        if (hipSetDevice(device) != hipSuccess) return pipe.fail(ZG_ERR_HIP, "hipSetDevice (reader)");
+        uint8_t carry = 0;
+        for (size_t k = 0;; k++) {
+            if (!pipe.wait([&] { return k < pipe.consumed + 2; })) return;
+            StreamIn &s = in[k & 1];
+            const StreamIn &prev = in[(k & 1) ^ 1];
+            s.halo = k ? halo_max : 0;  // a segment that has a successor is full
+            if (k) memcpy(s.h, prev.h + prev.halo + prev.n - s.halo, s.halo);
+            uint8_t *p = s.h + s.halo;
+            size_t n = 0;
+            if (k) p[n++] = carry;
+            bool eof = false;
+            while (n < seg && !eof) {
+                const size_t r = read_fn(read_user, p + n, seg - n);
+                if (r == (size_t)-1 || r > seg - n) return pipe.fail(ZG_ERR_IO, "the read callback failed");
+                eof = r == 0;
+                n += r;
+            }
+            if (!eof) {  // is there a byte behind this segment?  it opens the next one
+                const size_t r = read_fn(read_user, &carry, 1);
+                if (r == (size_t)-1 || r > 1) return pipe.fail(ZG_ERR_IO, "the read callback failed");
+                eof = r == 0;
+            }
+            s.n = n;
+            s.last = eof;
+            if (s.halo + n) {
+                hipError_t he = hipMemcpyAsync(s.d, s.h, s.halo + n, hipMemcpyHostToDevice, rs);
+                if (he == hipSuccess) he = hipStreamSynchronize(rs);
+                if (he != hipSuccess) return pipe.fail(ZG_ERR_HIP, hipGetErrorString(he));
+            }
+            n_in += n;
+            pipe.post([&] { pipe.filled = k + 1; });
+            if (eof) return;
+        }
+    };
+
+    auto writer = [&] {
+        if (hipSetDevice(device) != hipSuccess) return pipe.fail(ZG_ERR_HIP, "hipSetDevice (writer)");
+        uint8_t held = 0;
+        bool have_held = false;
+        for (size_t k = 0;; k++) {
+            if (!pipe.wait([&] { return pipe.packed > k; })) return;
+            StreamOut &s = out[k & 1];
+            if (s.h_cap < s.len + 8) {
+                if (s.h) (void)hipHostFree(s.h);
+                s.h = nullptr;
+                s.h_cap = s.len + (s.len >> 3) + 4096;
+                if (hipHostMalloc(reinterpret_cast<void **>(&s.h), s.h_cap, hipHostMallocDefault) != hipSuccess) {
+                    s.h_cap = 0;
+                    return pipe.fail(ZG_ERR_NOMEM, "pinned memory for the stream's bytes");
+                }
+            }
+            if (s.len) {
+                hipError_t he = hipMemcpyAsync(s.h, s.d.as<uint8_t>() + s.off, s.len, hipMemcpyDeviceToHost, ws);
+                if (he == hipSuccess) he = hipStreamSynchronize(ws);
+                if (he != hipSuccess) return pipe.fail(ZG_ERR_HIP, hipGetErrorString(he));
+            }
+            const bool last = s.last;
+            uint8_t *p = s.h;
+            size_t len = s.len;
+            if (s.clear_at >= 0 && (size_t)s.clear_at >= s.off && (size_t)s.clear_at - s.off < len)
+                p[(size_t)s.clear_at - s.off] &= 0xFE;
+            if (have_held) {
+                if (s.or_first && len) {
+                    p[0] |= held;
+                } else if (write_fn(write_user, &held, 1) != 0) {
+                    return pipe.fail(ZG_ERR_IO, "the write callback failed");
+                } else {
+                    n_out += 1;
+                }
+                have_held = false;
+            }
+            if (s.hold_last && len) {
+                held = p[--len];
+                have_held = true;
+            }
+            if (len && write_fn(write_user, p, len) != 0) return pipe.fail(ZG_ERR_IO, "the write callback failed");
+            n_out += len;
+            if (s.tail_n) {
+                if (write_fn(write_user, s.tail, s.tail_n) != 0) return pipe.fail(ZG_ERR_IO, "the write callback failed");
+                n_out += s.tail_n;
+            }
+            pipe.post([&] { pipe.written = k + 1; });
+            if (last) return;
+        }
+    };
+
+    std::thread rt, wt;
+    try {
+        rt = std::thread(reader);
+        wt = std::thread(writer);
+    } catch (...) {
+        pipe.fail(ZG_ERR_NOMEM, "no thread for the stream's reader or writer");
+    }
+
+    // this thread: the kernels
+    uint64_t bit = 16;
+    uint32_t adler = 1;
+    for (size_t k = 0;; k++) {
+        if (!pipe.wait([&] { return pipe.filled > k; })) break;
+        StreamIn &si = in[k & 1];
+        if (k == 0 && strategy == ZG_AUTO) {
+            // the length enters the choice below 8 KiB only; a first segment with a successor is longer than that
+            strategy = auto_choice(si.h, si.last ? si.n : std::max<size_t>(si.n + 1, 8192));
+        }
+        if (!pipe.wait([&] { return k < pipe.written + 2; })) break;
+        StreamOut &so = out[k & 1];
+        so = StreamOut{std::move(so.d), so.h, so.h_cap};
+        so.last = si.last;
+        int r = ZG_OK;
+        if (strategy == ZG_RAW) {
+            const size_t cap = (stored_size(si.n) + 3) & ~(size_t)3;
+            hipError_t he = so.d.ensure(cap);
+            if (he != hipSuccess) {
+                pipe.fail(fail_hip(c, he, "so.d.ensure"), "device memory for the stream's bytes");
+                break;
+            }
+            size_t got = 0;
+            r = compress_device_locked(c, static_cast<const uint8_t *>(si.d) + si.halo, si.n, ZG_RAW, opts,
+                                       so.d.as<uint8_t>(), cap, &got);
+            uint8_t t[4] = {0, 0, 0, 0};
+            if (!r && got >= 6 &&
+                hipMemcpy(t, so.d.as<uint8_t>() + got - 4, 4, hipMemcpyDeviceToHost) != hipSuccess)
+                r = ZG_ERR_HIP;
+            if (!r && got < 6) r = ZG_ERR_INTERNAL;
+            if (!r) {
+                const uint32_t a = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+                adler = k ? zg_adler32_combine(adler, a, si.n) : a;
+                so.off = k ? 2 : 0;
+                so.len = got - 4 - so.off;
+                const size_t nblk = si.n == 0 ? 1 : (si.n + kStoredBlock - 1) / kStoredBlock;
+                if (!si.last) so.clear_at = (int64_t)(2 + (nblk - 1) * (kStoredBlock + 5));
+                if (si.last) {
+                    so.tail_n = 4;
+                    for (int i = 0; i < 4; i++) so.tail[i] = (uint8_t)(adler >> (24 - 8 * i));
+                }
+            }
+        } else {
+            zg_shard_info info{};
+            r = shard_begin_locked(c, si.d, si.halo, si.n, strategy, opts, si.last ? 1 : 0, &info);
+            if (!r) {
+                adler = k ? zg_adler32_combine(adler, info.adler, si.n) : info.adler;
+                const uint64_t local0 = k ? (bit & 7) : 16;
+                const size_t need = (size_t)(((local0 + info.total_bits + 7) >> 3) + (si.last ? 4 : 0));
+                const size_t cap = (need + 3 + 8) & ~(size_t)3;
+                hipError_t he = so.d.ensure(cap);
+                if (he != hipSuccess) {
+                    pipe.fail(fail_hip(c, he, "so.d.ensure"), "device memory for the stream's bytes");
+                    break;
+                }
+                size_t nb = 0;
+                r = shard_finish_locked(c, bit, k == 0, si.last ? 1 : 0, adler, so.d.p, cap, &nb);
+                so.len = nb;
+                so.or_first = k != 0 && (bit & 7) != 0;
+                bit += info.total_bits;
+                so.hold_last = !si.last && (bit & 7) != 0;
+            }
+        }
+        if (r) {
+            pipe.fail(r, "a segment could not be compressed");
+            break;
+        }
+        const bool last = si.last;
+        pipe.post([&] {
+            pipe.consumed = k + 1;
+            pipe.packed = k + 1;
+        });
+        if (last) break;
+    }
+    if (rt.joinable()) rt.join();
+    if (wt.joinable()) wt.join();
+    release();
+    if (pipe.rc) {
+        if (pipe.rc != ZG_ERR_HIP || c->err.empty()) c->err = pipe.what;
+        return pipe.rc;
+    }
+    if (in_total) *in_total = n_in;
+    if (out_total) *out_total = n_out;
+    return ZG_OK;
+}
+
+size_t file_read(void *user, uint8_t *buf, size_t cap) {
+    FILE *f = static_cast<FILE *>(user);
+    const size_t r = fread(buf, 1, cap, f);
+    return (r == 0 && ferror(f)) ? (size_t)-1 : r;
+}
+int file_write(void *user, const uint8_t *buf, size_t n) {
+    return fwrite(buf, 1, n, static_cast<FILE *>(user)) == n ? 0 : -1;
+}
+}  // namespace
+
+extern "C" {
+
+int zg_compress_stream(zg_ctx *ctx, zg_read_fn read_fn, void *read_user, zg_write_fn write_fn, void *write_user,
+                       int strategy, const zg_opts *opts, uint64_t size_hint, uint64_t *in_total,
+                       uint64_t *out_total) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (!read_fn || !write_fn) return ZG_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return compress_stream_locked(c, read_fn, read_user, write_fn, write_user, strategy, opts, size_hint, in_total,
+                                  out_total);
+}
+
+int zg_compress_file(zg_ctx *ctx, const char *in_path, const char *out_path, int strategy, const zg_opts *opts,
+                     uint64_t *in_bytes, uint64_t *out_bytes) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (!in_path || !out_path) return ZG_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    FILE *fi = fopen(in_path, "rb");
+    if (!fi) {
+        c->err = std::string("cannot open ") + in_path;
+        return ZG_ERR_IO;
+    }
+    uint64_t hint = 0;
+    struct stat st;
+    if (fstat(fileno(fi), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) hint = (uint64_t)st.st_size;
+    FILE *fo = fopen(out_path, "wb");
+    if (!fo) {
+        fclose(fi);
+        c->err = std::string("cannot create ") + out_path;
+        return ZG_ERR_IO;
+    }
+    rc = compress_stream_locked(c, file_read, fi, file_write, fo, strategy, opts, hint, in_bytes, out_bytes);
+    fclose(fi);
+    if (fclose(fo) != 0 && !rc) {
+        c->err = std::string("cannot finish ") + out_path;
+        rc = ZG_ERR_IO;
+    }
+    return rc;
 }
 
 size_t zg_last_block_offsets(zg_ctx *ctx, uint64_t *bit_offsets, size_t cap) {
