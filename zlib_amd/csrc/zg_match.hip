@@ -32,6 +32,24 @@
 #define ZG_MATCH_STEPS 12
 #endif
 
+// -DZG_MATCH_DEBUG=1: phase times of k_match summed over its workgroups; =2: event counts as well (their atomics
+// slow the kernel down many times over).  tools/debug_match.py reads them.
+#ifdef ZG_MATCH_DEBUG
+__device__ unsigned long long g_mdbg[32];
+extern "C" int zg_match_debug_counters(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mdbg), sizeof(g_mdbg));
+}
+#define MDBG(...) __VA_ARGS__
+#if ZG_MATCH_DEBUG >= 2
+#define MDBG2(...) __VA_ARGS__
+#else
+#define MDBG2(...)
+#endif
+#else
+#define MDBG(...)
+#define MDBG2(...)
+#endif
+
 namespace zg {
 
 // ---------------------------------------------------------------------------
@@ -597,9 +615,12 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
         s_counter = 0;
         s_nopen = 0;
     }
+    MDBG(__shared__ unsigned long long s_t_exh; const unsigned long long t_begin = wall_clock64();
+         if (tid == 0) s_t_exh = 0;)
 
     stage_tile(data, next, base, w0, nbytes, nlinks, s_data, s_next, tid, G::threads, G::data_lds);
     __syncthreads();
+    MDBG(const unsigned long long t_staged = wall_clock64();)
 
     // Search.  Chain lengths are very uneven (Zipf-like), so positions are not bound to threads: a lane claims
     // the next unresolved position of the tile from an LDS counter whenever it finishes one.  Every iteration
@@ -682,15 +703,27 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
             const bool to_fetch = hd & (guard_end | (!survive & (nx == 0)));
             const bool to_eval = hd & !guard_end & survive;
             so += to_adv ? nx : 0u;
+            MDBG2(if (hd) atomicAdd(&g_mdbg[0], 1ull);)
             hd = to_adv & !to_fetch;
             ev |= to_eval;
             ft |= to_fetch;
         }
+        MDBG2(if ((tid & 63) == 0) atomicAdd(&g_mdbg[10], 1ull);)
         uint32_t n_head = (uint32_t)__popcll(__ballot(hd));
+        MDBG2(if ((tid & 63) == 0) {
+            if (*(volatile uint32_t *)&s_counter >= tn) {
+                atomicAdd(&g_mdbg[14], 1ull);
+                atomicAdd(&g_mdbg[16], (unsigned long long)n_head);
+            }
+            if (n_head <= 8) atomicAdd(&g_mdbg[15], 1ull);
+            if (n_head <= 2) atomicAdd(&g_mdbg[17], 1ull);
+        })
         uint32_t n_eval = (uint32_t)__popcll(__ballot(ev));
         // ---- measure surviving candidates ----
         if (n_eval >= kEvalBatch || (n_eval != 0 && n_head == 0)) {
+            MDBG2(if ((tid & 63) == 0) atomicAdd(&g_mdbg[11], 1ull);)
             if (ev) {
+                MDBG2(atomicAdd(&g_mdbg[2], 1ull);)
                 uint32_t m;
                 const uint32_t sc = so;  // chain position of the candidate
                 so += noff;              // the candidate itself
@@ -752,6 +785,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
             const uint32_t n_sw = (uint32_t)__popcll(__ballot(sw));
             if (n_sw >= kSwitchBatch || (n_sw != 0 && n_sw * 4 >= n_head)) {
                 if (sw) {
+                    MDBG2(atomicAdd(&g_mdbg[9], 1ull);)
                     const uint32_t o_old = st & 0xFFu, tchk = (st >> 8) & 0x1FFu;
                     const uint32_t room = pbase + tn - po;  // links are staged up to the end of the tile
                     uint32_t o_new = best - 5u;
@@ -791,6 +825,8 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                 // issue this visit's stores and, last, the loads for the next position.
                 uint32_t fd = nxt_far;
                 asm volatile("" : "+v"(fd));
+                MDBG2(if (__ffsll(__ballot(1)) - 1 == (int)(tid & 63)) atomicAdd(&g_mdbg[12], 1ull);)
+                MDBG2(atomicAdd(&g_mdbg[13], 1ull);)
                 if (has_pos) {
                     match_t[idx] = best ? ((best << 16) | bestd) : 0u;
                     if (best == 0u && emit_term) {  // still open: handed on to level 2
@@ -800,6 +836,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                 }
                 has_pos = false;
                 if (nxt_idx >= tn) {
+                    MDBG(if (s_t_exh == 0) s_t_exh = wall_clock64();)
                     ft = false;  // no positions left
                 } else {
                     idx = nxt_idx;
@@ -824,6 +861,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                         st = 0;
                         hd = true;
                         ft = false;
+                        MDBG2(atomicAdd(&g_mdbg[4], 1ull);)
                     }
                     need_sw = false;
                     nxt_idx = atomicAdd(&s_counter, 1u);
@@ -835,6 +873,14 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
             break;  // no lane has anything left
         }
     }
+    MDBG(const unsigned long long t_mine = wall_clock64(); __syncthreads(); if (tid == 0) {
+        const unsigned long long t_end = wall_clock64();
+        atomicAdd(&g_mdbg[20], t_end - t_begin);
+        atomicAdd(&g_mdbg[21], t_staged - t_begin);
+        atomicAdd(&g_mdbg[22], t_end - (s_t_exh ? s_t_exh : t_end));
+        atomicAdd(&g_mdbg[23], t_end - t_mine);
+        atomicAdd(&g_mdbg[24], 1ull);
+    })
     if (emit_term) {
         __syncthreads();
         if (tid == 0) open_cnt[bid] = s_nopen;
