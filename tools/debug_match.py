@@ -8,8 +8,12 @@ import zlib_amd as za
 from zlib_amd import _lib
 kind = sys.argv[1] if len(sys.argv) > 1 else "text"
 n = 64 << 20
-data = za.corpus(kind, n, seed=0x5EED0004)
-za.compress(data, za.Strategy.Dynamic)
+if kind == "recbatch":  # records of 4 KiB, each a stream of its own (the small match geometry)
+    data = za.corpus("records", n, seed=0x5EED0005)
+    za.compress_batch([data[i:i + 4096] for i in range(0, n, 4096)], za.Strategy.Dynamic)
+else:
+    data = za.corpus(kind, n, seed=0x5EED0004)
+    za.compress(data, za.Strategy.Dynamic)
 buf = (C.c_ulonglong * 32)()
 _lib.lib().zg_match_debug_counters(buf)
 v = list(buf)

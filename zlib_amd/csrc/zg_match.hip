@@ -31,6 +31,12 @@
 #ifndef ZG_MATCH_STEPS
 #define ZG_MATCH_STEPS 12
 #endif
+#ifndef ZG_MATCH_STEPS_REC
+#define ZG_MATCH_STEPS_REC 8
+#endif
+#ifndef ZG_MATCH_NEAR
+#define ZG_MATCH_NEAR 48  // candidates this close to the position are measured without a probe
+#endif
 
 // -DZG_MATCH_DEBUG=1: phase times of k_match summed over its workgroups; =2: event counts as well (their atomics
 // slow the kernel down many times over).  tools/debug_match.py reads them.
@@ -641,7 +647,9 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     const uint64_t tail_room = ce - t0;  // bytes from tile position 0 to the end of the chunk
     const uint32_t tail_room32 = tail_room < 0x7FFFFFFFull ? (uint32_t)tail_room : 0x7FFFFFFFu;
 
-    constexpr int kHeadSteps = ZG_MATCH_STEPS;  // head steps between checks of the deferred work
+    // head steps between checks of the deferred work; walks inside a record are short and meet a candidate to
+    // measure every few steps, so their trips are shorter
+    constexpr int kHeadSteps = G::tile == kMatchRecordTile ? ZG_MATCH_STEPS_REC : ZG_MATCH_STEPS;
 #ifndef ZG_EVAL_BATCH
 #define ZG_EVAL_BATCH 1
 #endif
@@ -649,14 +657,23 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
 #define ZG_FETCH_BATCH 2
 #endif
     constexpr uint32_t kEvalBatch = ZG_EVAL_BATCH, kFetchBatch = ZG_FETCH_BATCH;
+#ifndef ZG_SWITCH_HOPS
+#define ZG_SWITCH_HOPS 1
+#endif
+#ifndef ZG_SWITCH_NOFF
+#define ZG_SWITCH_NOFF 7   // offsets looked at when a walk changes chains
+#endif
+#ifndef ZG_SWITCH_GAIN4
+#define ZG_SWITCH_GAIN4 8  // quarters: the new chain's links must be this many times as long
+#endif
 #ifndef ZG_SWITCH_TRIPS
-#define ZG_SWITCH_TRIPS 4
+#define ZG_SWITCH_TRIPS 2
 #endif
 #ifndef ZG_SWITCH_EVERY
 #define ZG_SWITCH_EVERY 4
 #endif
 #ifndef ZG_SWITCH_REMAIN
-#define ZG_SWITCH_REMAIN 256
+#define ZG_SWITCH_REMAIN 48
 #endif
 #ifndef ZG_SWITCH_BATCH
 #define ZG_SWITCH_BATCH 4
@@ -689,10 +706,17 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     uint32_t nxt_idx = atomicAdd(&s_counter, 1u);
     uint32_t nxt_far = nxt_idx < tn ? far_t[nxt_idx] : 0u;
 
+    // Which candidates are measured.  One that beats the best length so far agrees with the position in the four
+    // bytes ending at offset `best`.  One that ends the search at distance d matches d - 1 bytes or more, so beyond
+    // kNear positions back it agrees in the first kNear bytes.  Either way it agrees in the four bytes ending at
+    // offset min(best, kNear - 1): that is the probe.  Only the candidates within kNear of the position are
+    // measured whatever they look like.
+    constexpr uint32_t kNear = ZG_MATCH_NEAR;
+    const uint32_t near = max_len < kNear ? max_len : kNear;
     for (;;) {
 #pragma unroll
         for (int step = 0; step < kHeadSteps; step++) {
-            // a candidate within max_len of the position may end the search whatever its length: it is always
+            // a candidate close to the position may end the search whatever its length: it is always
             // measured; one farther away only if it passes the probe
             const bool nearby = (int32_t)so >= so_near;
             const uint32_t w = lds_ld4(s_data, so + toff);
@@ -756,8 +780,9 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                     } else if (m > best) {
                         best = m;
                         bestd = d;
-                        pt = lds_ld4(s_data, po + m - 3);
-                        toff = m - 3 + noff;
+                        const uint32_t mp_ = m < kNear - 1u ? m : kNear - 1u;  // offset of the probe's last byte
+                        pt = lds_ld4(s_data, po + mp_ - 3);
+                        toff = mp_ - 3 + noff;
                         tmask = 0xFFFFFFFFu;
                         finish = m == cap;  // cannot be exceeded
                         need_sw = kSwitchTrips != 0 && m >= 6;
@@ -788,9 +813,34 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                     MDBG2(atomicAdd(&g_mdbg[9], 1ull);)
                     const uint32_t o_old = st & 0xFFu, tchk = (st >> 8) & 0x1FFu;
                     const uint32_t room = pbase + tn - po;  // links are staged up to the end of the tile
-                    uint32_t o_new = best - 5u;
-                    o_new = o_new < room ? o_new : room;
-                    o_new = o_new < 255u ? o_new : 255u;
+                    uint32_t o_hi = best - 5u;
+                    o_hi = o_hi < room ? o_hi : room;
+                    o_hi = o_hi < 255u ? o_hi : 255u;
+                    // Any offset up to best - 5 will do; the chain to take is the sparsest one, judged by how far
+                    // two links lead from the best candidate on each of them (the present chain included: a
+                    // change has to promise links at least twice as long).
+                    uint32_t o_new = o_old;
+#if ZG_SWITCH_HOPS
+                    {
+                        const uint32_t cb = po - bestd;  // the best candidate
+                        const uint32_t h1 = s_next[cb + o_old];
+                        uint32_t h_best = ((h1 + s_next[cb + o_old + h1]) * (uint32_t)ZG_SWITCH_GAIN4) >> 2;
+#pragma unroll
+                        for (uint32_t k = 0; k < (uint32_t)ZG_SWITCH_NOFF; k++) {
+                            const uint32_t o = o_hi - k;
+                            const bool ok = k <= o_hi && o > o_old;
+                            const uint32_t q = cb + (ok ? o : o_old);
+                            const uint32_t n1 = s_next[q];
+                            const uint32_t h = n1 + s_next[q + n1];
+                            if (ok && h > h_best) {
+                                h_best = h;
+                                o_new = o;
+                            }
+                        }
+                    }
+#else
+                    o_new = o_hi;
+#endif
                     if (o_new > o_old) {
                         int32_t end_u = so_end - (int32_t)o_old;
                         // a skipped candidate at distance d ends the search iff it matches max(rec_min, d - 1) bytes
@@ -805,10 +855,10 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                             }
                         }
                         so = po - bestd + o_new;
-                        so_near = (int32_t)po - (int32_t)max_len + (int32_t)o_new;
+                        so_near = (int32_t)po - (int32_t)near + (int32_t)o_new;
                         so_end = end_u + (int32_t)o_new;
                         noff = 0u - o_new;
-                        toff = best - 3u - o_new;
+                        toff = (best < kNear - 1u ? best : kNear - 1u) - 3u - o_new;
                         st = (best << 8) | o_new;  // trips start again
                     }
                     need_sw = false;
@@ -850,7 +900,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                     if (fd != 0 && remain32 > min_len && cap >= rec_min) {
                         po = pbase + idx;
                         so = po - fd;
-                        so_near = (int32_t)po - (int32_t)max_len;
+                        so_near = (int32_t)po - (int32_t)near;
                         so_end = (int32_t)po - (int32_t)min_len;
                         p0 = lds_ld4(s_data, po);
                         p1 = lds_ld4(s_data, po + 4);
