@@ -22,3 +22,4 @@ print(f"wave trips {v[10]}: head-step slots used {v[0] / max(1, v[10] * 64 * 12)
 print(f"trips after the tile's last position was claimed: {v[14] / max(1, v[10]):.3f} of all ({v[16] / max(1, v[14]):.1f} walking lanes); trips with at most 8 walking lanes {v[15] / max(1, v[10]):.3f}, at most 2: {v[17] / max(1, v[10]):.3f}")
 wg = max(1, v[24])
 print(f"per workgroup (100 MHz ticks): whole {v[20] / wg:.0f}, staging {v[21] / wg:.0f} ({v[21] / max(1, v[20]):.2f}), from the first failed claim to the end {v[22] / wg:.0f} ({v[22] / max(1, v[20]):.2f}), first wave waiting for the last {v[23] / wg:.0f}")
+print(f"walks finished by the whole wave: {v[18]}")

@@ -34,6 +34,15 @@
 #ifndef ZG_MATCH_STEPS_REC
 #define ZG_MATCH_STEPS_REC 8
 #endif
+#ifndef ZG_MATCH_COOP_LANES
+#define ZG_MATCH_COOP_LANES 2  // a draining wave with at most this many walking lanes finishes long walks together; 0: never
+#endif
+#ifndef ZG_MATCH_COOP_GAIN
+#define ZG_MATCH_COOP_GAIN 8   // ... by this factor (the comparison stalls the wave's other walks and measures every true candidate)
+#endif
+#ifndef ZG_MATCH_COOP_BASE
+#define ZG_MATCH_COOP_BASE 3   // ... those expected to take more than this many trips plus one per 2 KiB left
+#endif
 #ifndef ZG_MATCH_NEAR
 #define ZG_MATCH_NEAR 48  // candidates this close to the position are measured without a probe
 #endif
@@ -702,6 +711,8 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     bool need_sw = false; // best has grown since the chain was chosen
     uint32_t round = 0;   // trips of the workgroup's loop (uniform)
     uint32_t termd = 0;                        // distance of the candidate that ended the search, if one did
+    uint32_t dref = 0;                         // distance of the candidate the trips in `st` are counted from
+    bool drain = false;                        // uniform: a lane of this wave has found no position left to claim
     bool has_pos = false;  // a position is loaded and its result is not yet written
     uint32_t nxt_idx = atomicAdd(&s_counter, 1u);
     uint32_t nxt_far = nxt_idx < tn ? far_t[nxt_idx] : 0u;
@@ -712,6 +723,8 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     // offset min(best, kNear - 1): that is the probe.  Only the candidates within kNear of the position are
     // measured whatever they look like.
     constexpr uint32_t kNear = ZG_MATCH_NEAR;
+    // (not inside records: their chains are short)
+    constexpr uint32_t kCoopLanes = G::tile == kMatchRecordTile ? 0u : (uint32_t)ZG_MATCH_COOP_LANES, kCoopBase = ZG_MATCH_COOP_BASE, kCoopGain = ZG_MATCH_COOP_GAIN;
     const uint32_t near = max_len < kNear ? max_len : kNear;
     for (;;) {
 #pragma unroll
@@ -787,6 +800,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                         finish = m == cap;  // cannot be exceeded
                         need_sw = kSwitchTrips != 0 && m >= 6;
                         st &= 0x1FFFFu;  // trips are counted from the best candidate on
+                        dref = d;
                     }
                 }
                 const uint32_t nx = s_next[sc];
@@ -804,7 +818,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
         if (kSwitchTrips != 0 && (round & (ZG_SWITCH_EVERY - 1)) == 0) {  // looked at every few trips only
             // worth it when the chain walked now is dense: at the rate of members per byte seen since the best
             // candidate, more than kSwitchRemain steps are left before the position
-            const uint32_t trips = st >> 17, dcur = po - so - noff, cov = bestd - dcur;
+            const uint32_t trips = st >> 17, dcur = po - so - noff, cov = (kCoopLanes != 0 ? dref : bestd) - dcur;
             const bool sw = hd & need_sw & (trips >= kSwitchTrips) &
                             (trips * (uint32_t)kHeadSteps * (dcur >> 4) >= kSwitchRemain * (cov >> 4));
             const uint32_t n_sw = (uint32_t)__popcll(__ballot(sw));
@@ -860,6 +874,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                         noff = 0u - o_new;
                         toff = (best < kNear - 1u ? best : kNear - 1u) - 3u - o_new;
                         st = (best << 8) | o_new;  // trips start again
+                        dref = bestd;
                     }
                     need_sw = false;
                 }
@@ -869,6 +884,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
         // ---- retire finished positions and claim new ones ----
         const uint32_t n_fetch = (uint32_t)__popcll(__ballot(ft));
         if (n_fetch >= kFetchBatch || (n_fetch != 0 && n_head == 0 && n_eval == 0)) {
+            bool gone = false;
             if (ft) {
                 // Order matters for the memory counter, which retires in issue order: first take the values
                 // prefetched by the previous visit (nothing younger is in flight, so this costs no wait), then
@@ -887,6 +903,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                 has_pos = false;
                 if (nxt_idx >= tn) {
                     MDBG(if (s_t_exh == 0) s_t_exh = wall_clock64();)
+                    gone = true;
                     ft = false;  // no positions left
                 } else {
                     idx = nxt_idx;
@@ -900,6 +917,7 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                     if (fd != 0 && remain32 > min_len && cap >= rec_min) {
                         po = pbase + idx;
                         so = po - fd;
+                        dref = fd;
                         so_near = (int32_t)po - (int32_t)near;
                         so_end = (int32_t)po - (int32_t)min_len;
                         p0 = lds_ld4(s_data, po);
@@ -919,8 +937,44 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                     nxt_far = far_t[ni];
                 }
             }
+            drain = drain || __ballot(gone) != 0;
         } else if (n_fetch == 0 && n_head == 0 && n_eval == 0) {
             break;  // no lane has anything left
+        }
+        // ---- the end of the tile: long walks are finished by the whole wave ----
+        // When the tile has no position left to claim, the lanes of a wave fall idle one by one while a few walks
+        // go on, and the workgroup lasts as long as its longest one -- hundreds of trips for a rare key in the
+        // bucket of a frequent one.  A wave with at most kCoopLanes lanes still walking therefore takes over
+        // every walk whose remaining steps (members per byte so far x bytes left) would take longer than
+        // comparing the rest of the window directly, sixteen candidates per lane and round (wave_search: the
+        // same candidates in the same order under the same rules, so the same answer).
+        if (kCoopLanes != 0 && drain && (round & 3u) == 0 && n_head != 0 && n_head <= kCoopLanes) {
+            {
+                const uint32_t trips = st >> 17, dcur = po - so - noff, cov = dref - dcur;
+                const bool coop = hd & (trips >= 2u) & (trips * dcur >= kCoopGain * (kCoopBase + (dcur >> 11)) * cov);
+                uint64_t todo = __ballot(coop);
+                while (todo) {
+                    const int l = __ffsll((unsigned long long)todo) - 1;
+                    todo &= todo - 1;
+                    const uint32_t c_lo = (uint32_t)__builtin_amdgcn_readlane((int)(so + noff), l);
+                    const uint32_t c_hi = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)so_end + noff), l);
+                    const uint32_t ppo = (uint32_t)__builtin_amdgcn_readlane((int)po, l);
+                    const uint32_t pp0 = (uint32_t)__builtin_amdgcn_readlane((int)p0, l);
+                    const uint32_t pcap = (uint32_t)__builtin_amdgcn_readlane((int)cap, l);
+                    uint32_t wb = (uint32_t)__builtin_amdgcn_readlane((int)best, l);
+                    uint32_t wbd = (uint32_t)__builtin_amdgcn_readlane((int)bestd, l);
+                    uint32_t wt = (uint32_t)__builtin_amdgcn_readlane((int)termd, l);
+                    wave_search(s_data, c_lo, c_hi, ppo, pp0, pcap, rec_min, max_len, tid & 63u, wb, wbd, wt);
+                    if ((tid & 63u) == (uint32_t)l) {
+                        best = wb;
+                        bestd = wbd;
+                        termd = wt;
+                        hd = false;
+                        ft = true;  // retired by the next visit of the claim block
+                    }
+                    MDBG2(if ((tid & 63u) == (uint32_t)l) atomicAdd(&g_mdbg[18], 1ull);)
+                }
+            }
         }
     }
     MDBG(const unsigned long long t_mine = wall_clock64(); __syncthreads(); if (tid == 0) {

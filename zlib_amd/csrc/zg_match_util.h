@@ -110,4 +110,88 @@ __device__ __forceinline__ uint32_t scan16(const uint8_t *s_data, uint32_t a, ui
     return h;
 }
 
+constexpr uint32_t kNoCandidate = 0xFFFFFFFFu;
+
+// the sixteen candidates a .. a + 15 (a a multiple of 16): bit j is set when candidate a + j lies in [lo, hi) and
+// its first four bytes equal p0
+__device__ __forceinline__ uint32_t match16(const uint8_t *s_data, uint32_t a, uint32_t p0, uint32_t lo, uint32_t hi) {
+    if (a >= hi || a + 16u <= lo) return 0u;
+    const uint4 q = *reinterpret_cast<const uint4 *>(s_data + a);
+    const uint32_t w[5] = {q.x, q.y, q.z, q.w, *reinterpret_cast<const uint32_t *>(s_data + a + 16)};
+    uint32_t mask = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t v = (j & 3) == 0 ? w[j >> 2] : __builtin_amdgcn_alignbyte(w[(j >> 2) + 1], w[j >> 2], (uint32_t)(j & 3));
+        mask |= (v == p0 ? 1u : 0u) << j;
+    }
+    const uint32_t below = lo > a ? (1u << (lo - a)) - 1u : 0u;           // candidates under lo
+    const uint32_t upto = hi - a < 16u ? (1u << (hi - a)) - 1u : 0xFFFFu;  // candidates under hi
+    return mask & upto & ~below;
+}
+
+// The rest of a level-1 search by the whole wave: every candidate of [c_lo, c_hi) whose first four bytes equal the
+// position's is measured, in the reference's ascending order and under its rules (see k_match): a candidate of
+// rec_min bytes or more ends the search when its growing match reaches the position (distance <= length + 1,
+// within max_len), is recorded when it is strictly longer than the best so far, and ends the search when it
+// cannot be exceeded (length == cap).  All arguments are uniform over the wave; best / bestd / termd are the
+// walk's state so far and receive the result.
+__device__ __forceinline__ void wave_search(const uint8_t *s_data, uint32_t c_lo, uint32_t c_hi, uint32_t ppo,
+                                            uint32_t pp0, uint32_t cap, uint32_t rec_min, uint32_t max_len,
+                                            uint32_t lane, uint32_t &best, uint32_t &bestd, uint32_t &termd) {
+    for (uint32_t b0 = c_lo & ~15u; b0 < c_hi; b0 += 1024) {
+        const uint32_t a = b0 + lane * 16;
+        uint32_t hits = match16(s_data, a, pp0, c_lo, c_hi);
+        uint32_t lm = 0, ls = 0, lstop = kNoCandidate;  // my longest candidate and where my range stops the search
+        bool lterm = false;
+        while (hits) {
+            const uint32_t s = a + (uint32_t)__builtin_ctz(hits);
+            hits &= hits - 1;
+            uint32_t m = 4;
+            while (m < cap) {
+                const uint32_t x = lds_ld4(s_data, s + m) ^ lds_ld4(s_data, ppo + m);
+                if (x) {
+                    m += (uint32_t)__builtin_ctz(x) >> 3;
+                    break;
+                }
+                m += 4;
+            }
+            if (m > cap) m = cap;
+            if (m < rec_min) continue;
+            const uint32_t d = ppo - s;
+            if (d <= max_len && m + 1 >= d) {  // the growing match reaches the position
+                lstop = s;
+                lterm = true;
+                break;
+            }
+            if (m > lm) {
+                lm = m;
+                ls = s;
+            }
+            if (m == cap) {  // cannot be exceeded: recorded (it beats whatever came before) and the search ends
+                lstop = s;
+                break;
+            }
+        }
+        // lanes hold ascending ranges: everything behind the first stopping lane is never looked at
+        const uint64_t stops = __ballot(lstop != kNoCandidate);
+        const uint32_t tl = stops ? (uint32_t)__ffsll((unsigned long long)stops) - 1u : 64u;
+        const uint32_t em = lane <= tl ? lm : 0u;
+        uint32_t wm = em;
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)wm, off);
+            wm = o > wm ? o : wm;
+        }
+        if (wm > best) {  // strictly longer than everything farther away; ties inside the round go to the lowest lane
+            const uint64_t who = __ballot(em == wm);
+            const int src = __ffsll((unsigned long long)who) - 1;
+            best = wm;
+            bestd = ppo - (uint32_t)__shfl((int)ls, src);
+        }
+        if (stops) {
+            if (__shfl((int)lterm, (int)tl)) termd = ppo - (uint32_t)__shfl((int)lstop, (int)tl);
+            break;
+        }
+    }
+}
+
 }  // namespace zg

@@ -92,88 +92,6 @@ __device__ __forceinline__ uint32_t wave_scan(const uint8_t *s_data, uint32_t s_
     return hit;
 }
 
-// the sixteen candidates a .. a + 15 (a a multiple of 16): bit j is set when candidate a + j lies in [lo, hi) and
-// its first four bytes equal p0
-__device__ __forceinline__ uint32_t match16(const uint8_t *s_data, uint32_t a, uint32_t p0, uint32_t lo, uint32_t hi) {
-    if (a >= hi || a + 16u <= lo) return 0u;
-    const uint4 q = *reinterpret_cast<const uint4 *>(s_data + a);
-    const uint32_t w[5] = {q.x, q.y, q.z, q.w, *reinterpret_cast<const uint32_t *>(s_data + a + 16)};
-    uint32_t mask = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const uint32_t v = (j & 3) == 0 ? w[j >> 2] : __builtin_amdgcn_alignbyte(w[(j >> 2) + 1], w[j >> 2], (uint32_t)(j & 3));
-        mask |= (v == p0 ? 1u : 0u) << j;
-    }
-    const uint32_t below = lo > a ? (1u << (lo - a)) - 1u : 0u;           // candidates under lo
-    const uint32_t upto = hi - a < 16u ? (1u << (hi - a)) - 1u : 0xFFFFu;  // candidates under hi
-    return mask & upto & ~below;
-}
-
-// The rest of a level-1 search by the whole wave: every candidate of [c_lo, c_hi) whose first four bytes equal the
-// position's is measured, in the reference's ascending order and under its rules (see k_match): a candidate of
-// rec_min bytes or more ends the search when its growing match reaches the position (distance <= length + 1,
-// within max_len), is recorded when it is strictly longer than the best so far, and ends the search when it
-// cannot be exceeded (length == cap).  All arguments are uniform over the wave; best / bestd / termd are the
-// walk's state so far and receive the result.
-__device__ __forceinline__ void wave_search(const uint8_t *s_data, uint32_t c_lo, uint32_t c_hi, uint32_t ppo,
-                                            uint32_t pp0, uint32_t cap, uint32_t rec_min, uint32_t max_len,
-                                            uint32_t lane, uint32_t &best, uint32_t &bestd, uint32_t &termd) {
-    for (uint32_t b0 = c_lo & ~15u; b0 < c_hi; b0 += 1024) {
-        const uint32_t a = b0 + lane * 16;
-        uint32_t hits = match16(s_data, a, pp0, c_lo, c_hi);
-        uint32_t lm = 0, ls = 0, lstop = kNoPos;  // my longest candidate and where my range stops the search
-        bool lterm = false;
-        while (hits) {
-            const uint32_t s = a + (uint32_t)__builtin_ctz(hits);
-            hits &= hits - 1;
-            uint32_t m = 4;
-            while (m < cap) {
-                const uint32_t x = lds_ld4(s_data, s + m) ^ lds_ld4(s_data, ppo + m);
-                if (x) {
-                    m += (uint32_t)__builtin_ctz(x) >> 3;
-                    break;
-                }
-                m += 4;
-            }
-            if (m > cap) m = cap;
-            if (m < rec_min) continue;
-            const uint32_t d = ppo - s;
-            if (d <= max_len && m + 1 >= d) {  // the growing match reaches the position
-                lstop = s;
-                lterm = true;
-                break;
-            }
-            if (m > lm) {
-                lm = m;
-                ls = s;
-            }
-            if (m == cap) {  // cannot be exceeded: recorded (it beats whatever came before) and the search ends
-                lstop = s;
-                break;
-            }
-        }
-        // lanes hold ascending ranges: everything behind the first stopping lane is never looked at
-        const uint64_t stops = __ballot(lstop != kNoPos);
-        const uint32_t tl = stops ? (uint32_t)__ffsll((unsigned long long)stops) - 1u : 64u;
-        const uint32_t em = lane <= tl ? lm : 0u;
-        uint32_t wm = em;
-        for (int off = 32; off > 0; off >>= 1) {
-            const uint32_t o = (uint32_t)__shfl_xor((int)wm, off);
-            wm = o > wm ? o : wm;
-        }
-        if (wm > best) {  // strictly longer than everything farther away; ties inside the round go to the lowest lane
-            const uint64_t who = __ballot(em == wm);
-            const int src = __ffsll((unsigned long long)who) - 1;
-            best = wm;
-            bestd = ppo - (uint32_t)__shfl((int)ls, src);
-        }
-        if (stops) {
-            if (__shfl((int)lterm, (int)tl)) termd = ppo - (uint32_t)__shfl((int)lstop, (int)tl);
-            break;
-        }
-    }
-}
-
 // reads n 16-bit elements from p on (one word per 128-byte line), to no purpose but to have them in the L2 when
 // the walks ask for them; the values are only summed, so that no load is waited for before the caller's own
 // loads have been issued
@@ -702,31 +620,64 @@ uint32_t walk_tiles_per_run(const ChunkGrid &g, uint32_t n_chunks, uint32_t cus)
     return (uint32_t)r;
 }
 
+// Which search for a chunk?  The search along the parse pays where chains are long AND matches are long, so that
+// the parse stands on few positions, each with a long search (log lines, records of a fixed layout with text in
+// them: 4 x on generated log lines); with long chains and short matches (packed binary records) the search of every
+// position is as fast now that its long walks change to sparser chains, and where the first candidate already
+// matches everything there is to match (runs, short periods) every search ends at once.  So a chunk goes along the parse
+// when, over 256 sampled positions, the mean estimated chain length exceeds ZG_PROBE_THRESHOLD and the mean of the longest
+// common prefix with one of the chain's first eight members (counted up to kProbeLcp bytes) lies in
+// [ZG_PROBE_LCP_LO, ZG_PROBE_LCP_HI).
 #ifndef ZG_PROBE_THRESHOLD
 #define ZG_PROBE_THRESHOLD 96
 #endif
+#ifndef ZG_PROBE_LCP_LO
+#define ZG_PROBE_LCP_LO 16
+#endif
+#ifndef ZG_PROBE_LCP_HI
+#define ZG_PROBE_LCP_HI 56
+#endif
 constexpr uint32_t kProbeSteps = 8;  // members of a sampled chain that are walked; the rest is extrapolated
+constexpr uint32_t kProbeLcp = 64;
 
-__global__ __launch_bounds__(256) void k_chunk_probe(uint64_t first, uint64_t end, uint64_t chunk_bytes,
-                                                      const uint32_t *__restrict__ clen, uint32_t c0,
-                                                      const uint16_t *__restrict__ far5,
+__global__ __launch_bounds__(256) void k_chunk_probe(const uint8_t *__restrict__ data, uint64_t first, uint64_t end,
+                                                      uint64_t chunk_bytes, const uint32_t *__restrict__ clen,
+                                                      uint32_t c0, const uint16_t *__restrict__ far5,
                                                       const uint16_t *__restrict__ next5, uint64_t base,
-                                                      uint8_t *__restrict__ walk_chunk, uint32_t threshold) {
-    __shared__ uint32_t s_sum[4];
+                                                      uint8_t *__restrict__ walk_chunk, uint32_t threshold,
+                                                      uint32_t lcp_lo, uint32_t lcp_hi) {
+    __shared__ uint32_t s_sum[4], s_lcp[4];
     const uint32_t ci = blockIdx.x, tid = threadIdx.x;
     const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
     const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
     const uint64_t len = ce - cs;
     uint32_t steps = 0;  // (estimated) members of the sampled position's chain inside its window
+    uint32_t longest = 0;  // most bytes (up to kProbeLcp) one of the chain's first members has in common with the position
     if (len >= 256) {
         // 256 positions spread over the chunk, each moved by a pseudo-random amount inside its stretch: evenly
         // spaced samples would all fall on the same field of fixed-size records
         const uint64_t stretch = len / 256;
         const uint64_t p = cs + stretch * tid + ((tid * 2654435761u) >> 8) % stretch;
         const uint32_t fd = far5[p - base];
+        const bool measure = p + kProbeLcp + 8 <= ce;
         uint64_t s = p - fd;
         while (fd != 0 && s < p && steps < kProbeSteps) {
             steps++;
+            if (measure) {
+                uint32_t m = 0;
+                while (m < kProbeLcp) {
+                    uint64_t x, y;
+                    __builtin_memcpy(&x, data + s + m, 8);
+                    __builtin_memcpy(&y, data + p + m, 8);
+                    if (x != y) {
+                        m += (uint32_t)__builtin_ctzll(x ^ y) >> 3;
+                        break;
+                    }
+                    m += 8;
+                }
+                m = m < kProbeLcp ? m : kProbeLcp;
+                longest = m > longest ? m : longest;
+            }
             const uint32_t nx = next5[s - base];
             if (nx == 0) break;
             s += nx;
@@ -734,12 +685,21 @@ __global__ __launch_bounds__(256) void k_chunk_probe(uint64_t first, uint64_t en
         // a chain that goes on is taken to keep the spacing of its first members up to the position
         if (steps == kProbeSteps && s < p) steps = (uint32_t)((uint64_t)fd * kProbeSteps / (s - (p - fd)));
     }
-    for (int off = 32; off > 0; off >>= 1) steps += __shfl_down(steps, off);
-    if ((tid & 63) == 0) s_sum[tid >> 6] = steps;
+    for (int off = 32; off > 0; off >>= 1) {
+        steps += __shfl_down(steps, off);
+        longest += __shfl_down(longest, off);
+    }
+    if ((tid & 63) == 0) {
+        s_sum[tid >> 6] = steps;
+        s_lcp[tid >> 6] = longest;
+    }
     __syncthreads();
-    if (tid == 0) walk_chunk[ci] = (s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]) > threshold * 256u ? 1 : 0;
+    if (tid == 0) {
+        const uint32_t chain = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        const uint32_t lcp = s_lcp[0] + s_lcp[1] + s_lcp[2] + s_lcp[3];
+        walk_chunk[ci] = (chain > threshold * 256u && lcp >= lcp_lo * 256u && lcp < lcp_hi * 256u) ? 1 : 0;
+    }
 }
-
 hipError_t launch_chunk_probe(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint16_t *far5,
                               const uint16_t *next5, uint64_t base, uint8_t *walk_chunk, hipStream_t s) {
     if (c1 <= c0) return hipSuccess;
@@ -748,8 +708,9 @@ hipError_t launch_chunk_probe(const ChunkGrid &g, uint32_t c0, uint32_t c1, cons
         const int v = e ? atoi(e) : 0;
         return (uint32_t)(v > 0 ? v : ZG_PROBE_THRESHOLD);
     }();
-    hipLaunchKernelGGL(k_chunk_probe, dim3(c1 - c0), dim3(256), 0, s, g.first, g.end, g.chunk_bytes, g.chunk_len, c0,
-                       far5, next5, base, walk_chunk, threshold);
+    hipLaunchKernelGGL(k_chunk_probe, dim3(c1 - c0), dim3(256), 0, s, g.data, g.first, g.end, g.chunk_bytes,
+                       g.chunk_len, c0, far5, next5, base, walk_chunk, threshold, (uint32_t)ZG_PROBE_LCP_LO,
+                       (uint32_t)ZG_PROBE_LCP_HI);
     return hipGetLastError();
 }
 
