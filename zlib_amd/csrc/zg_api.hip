@@ -348,6 +348,10 @@ int run_back(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, uint32_t m
                                         c->stream));
     LAUNCH(K_OFFSETS, launch_offsets(c1 - c0, max_tiles, c->ntok.as<uint32_t>(), c->tile_bits.as<uint32_t>(),
                                      c->block_bits.as<uint64_t>(), c->bit_off.as<uint64_t>(), &sc->carry, c->stream));
+    // the words k_encode ORs into; the rest of the output needs no clearing
+    LAUNCH(K_OFFSETS, launch_zero_seams(c1 - c0, max_tiles, c->ntok.as<uint32_t>(), c->hdr_bits.as<uint32_t>(),
+                                        c->tile_bits.as<uint32_t>(), c->bit_off.as<uint64_t>(),
+                                        c->block_bits.as<uint64_t>(), out, out_cap_bits, c->stream));
     LAUNCH(K_ENCODE, launch_encode(c1 - c0, max_tiles, c->tokens.as<uint32_t>(), g, c0, bs, c->ntok.as<uint32_t>(),
                                    c->tab.as<uint32_t>(), c->hdr.as<uint32_t>(), c->hdr_bits.as<uint32_t>(),
                                    c->tile_bits.as<uint32_t>(), c->bit_off.as<uint64_t>(), out, out_cap_bits,
@@ -472,7 +476,8 @@ int compress_device_once(zg_ctx *c, const uint8_t *d_in, size_t n, int strategy,
         } catch (...) {
             return ZG_ERR_NOMEM;
         }
-        LAUNCH(K_MISC, hipMemsetAsync(d_out, 0, bound, c->stream));
+        // the word the first block begins in; k_zero_seams clears the other words that are ORed into
+        LAUNCH(K_MISC, hipMemsetAsync(d_out, 0, std::min<size_t>(bound, 8), c->stream));
         const MatchParams mp{kMaxWindow, 3, 258};  // get_zlib_compressor, src/compress.rs:451-456
         rc = upload((size_t)std::min<uint64_t>(g.n_chunks, bc) * plan.chunk_bytes);
         if (rc) return rc;
@@ -1166,7 +1171,7 @@ int shard_begin_locked(zg_ctx *c, const void *d_in, size_t halo, size_t n, int s
         } catch (...) {
             return ZG_ERR_NOMEM;
         }
-        LAUNCH(K_MISC, hipMemsetAsync(c->shard_buf.p, 0, bound + 8, c->stream));
+        LAUNCH(K_MISC, hipMemsetAsync(c->shard_buf.p, 0, 8, c->stream));  // see compress_device_once
         for (uint32_t c0 = 0; c0 < g.n_chunks; c0 += (uint32_t)bc) {
             const uint32_t c1 = (uint32_t)std::min<uint64_t>(g.n_chunks, (uint64_t)c0 + bc);
             const int64_t final_chunk = (last_rank && c1 == g.n_chunks) ? (int64_t)(c1 - c0 - 1) : -1;

@@ -977,6 +977,53 @@ __global__ __launch_bounds__(kEncThreads) void k_encode(uint32_t max_tiles, cons
     }
 }
 
+// k_zero_seams: k_encode stores the interior words of a tile's bit range and ORs into its first and last word
+// and into the words of the block header, which it shares with its neighbours.  Only those words have to be zero
+// beforehand, not the whole output: for every block the words from the first one that begins inside it up to the
+// one its first tile starts in (the header's), and for every tile the word its range ends in (and the one before,
+// should the range end on a word boundary).  The word a block
+// begins in the middle of is the end word of the tile before it -- of this batch, of the batch before (zeroed then,
+// and already ORed into: it must not be touched again), or the first word of the output, which the caller zeroes.
+__global__ __launch_bounds__(256) void k_zero_seams(uint32_t max_tiles, const uint32_t *__restrict__ ntok,
+                                                     const uint32_t *__restrict__ hdr_bits,
+                                                     const uint32_t *__restrict__ tile_off,
+                                                     const uint64_t *__restrict__ bit_off,
+                                                     const uint64_t *__restrict__ block_bits, uint32_t *out,
+                                                     uint64_t out_cap_bits) {
+    const uint32_t ci = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t nt = (ntok[ci] + 1u + kEncTile - 1) / kEncTile;
+    const uint64_t blk_bit = bit_off[ci], last_word = out_cap_bits >> 5;
+    // the word this batch begins in the middle of holds bits of the batch before: never cleared here, even when a
+    // short block ends in it
+    const uint64_t keep = (bit_off[0] & 31u) ? bit_off[0] >> 5 : ~0ull;
+    const uint32_t hb = hdr_bits[ci];
+    if (blockIdx.x == 0) {
+        const uint64_t w_hi = (blk_bit + hb) >> 5;
+        for (uint64_t w = ((blk_bit + 31) >> 5) + threadIdx.x; w <= w_hi && w <= last_word; w += 256)
+            if (w != keep) out[w] = 0;
+    }
+    if (t < nt) {
+        const uint64_t start_bit = blk_bit + hb + tile_off[(uint64_t)ci * max_tiles + t];
+        const uint64_t end_bit = blk_bit + (t + 1 < nt ? (uint64_t)hb + tile_off[(uint64_t)ci * max_tiles + t + 1]
+                                                      : block_bits[ci]);
+        const uint64_t w = end_bit >> 5;
+        if (w <= last_word && w != keep) out[w] = 0;
+        // a range that ends on a word boundary: its last word is ORed into all the same (unless it is also its first
+        // word, which the tile before or the header's span has cleared)
+        if ((end_bit & 31u) == 0 && w > (start_bit >> 5) + 1 && w - 1 <= last_word && w - 1 != keep) out[w - 1] = 0;
+    }
+}
+
+hipError_t launch_zero_seams(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *ntok, const uint32_t *hdr_bits,
+                             const uint32_t *tile_off, const uint64_t *bit_off, const uint64_t *block_bits,
+                             uint32_t *out, uint64_t out_cap_bits, hipStream_t s) {
+    if (!n_chunks) return hipSuccess;
+    hipLaunchKernelGGL(k_zero_seams, dim3((max_tiles + 255) / 256, n_chunks), dim3(256), 0, s, max_tiles, ntok, hdr_bits,
+                       tile_off, bit_off, block_bits, out, out_cap_bits);
+    return hipGetLastError();
+}
+
 hipError_t launch_encode(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *tokens, const ChunkGrid &g,
                          uint32_t c0, uint64_t tok_base, const uint32_t *ntok, const uint32_t *tab,
                          const uint32_t *hdr, const uint32_t *hdr_bits, const uint32_t *tile_off,

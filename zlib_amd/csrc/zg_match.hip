@@ -43,6 +43,9 @@
 #ifndef ZG_MATCH_COOP_BASE
 #define ZG_MATCH_COOP_BASE 3   // ... those expected to take more than this many trips plus one per 2 KiB left
 #endif
+#ifndef ZG_MATCH_LATE
+#define ZG_MATCH_LATE 0  // positions at the end of a 16 Ki tile that are claimed without holding the claim ahead
+#endif
 #ifndef ZG_MATCH_NEAR
 #define ZG_MATCH_NEAR 48  // candidates this close to the position are measured without a probe
 #endif
@@ -604,6 +607,13 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     __shared__ __attribute__((aligned(16))) uint8_t s_mem[G::data_lds + 2 * G::next_lds];
     __shared__ uint32_t s_counter;  // next unclaimed position of the tile
     __shared__ uint32_t s_nopen;    // positions handed on to level 2
+    // far[] of the tile's last kLate positions.  A lane holds its next claim ahead of need, so that the position's
+    // far[] entry is on its way from memory while the current walk runs -- but when the tile runs out, every lane
+    // then has two walks left while idle lanes have none.  In the last part of the tile positions are therefore
+    // claimed only when needed, their far[] entries taken from this copy.
+    // (Records only: 5 % there; the large tiles lose a little by it.)
+    constexpr uint32_t kLate = G::tile >= 16384u ? (uint32_t)ZG_MATCH_LATE : G::tile / 4u;
+    __shared__ uint16_t s_far_late[kLate ? kLate : 1u];
     uint8_t *const s_data = s_mem;
     uint16_t *const s_next = reinterpret_cast<uint16_t *>(s_mem + G::data_lds);
 
@@ -633,6 +643,8 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     MDBG(__shared__ unsigned long long s_t_exh; const unsigned long long t_begin = wall_clock64();
          if (tid == 0) s_t_exh = 0;)
 
+    const uint32_t late0 = (uint32_t)(t1 - t0) > kLate ? (uint32_t)(t1 - t0) - kLate : 0u;
+    for (uint32_t i = tid; late0 + i < (uint32_t)(t1 - t0); i += G::threads) s_far_late[i] = far[(t0 - base) + late0 + i];
     stage_tile(data, next, base, w0, nbytes, nlinks, s_data, s_next, tid, G::threads, G::data_lds);
     __syncthreads();
     MDBG(const unsigned long long t_staged = wall_clock64();)
@@ -714,7 +726,8 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
     uint32_t dref = 0;                         // distance of the candidate the trips in `st` are counted from
     bool drain = false;                        // uniform: a lane of this wave has found no position left to claim
     bool has_pos = false;  // a position is loaded and its result is not yet written
-    uint32_t nxt_idx = atomicAdd(&s_counter, 1u);
+    constexpr uint32_t kNoClaim = 0xFFFFFFFFu;  // nxt_idx: no claim is held
+    uint32_t nxt_idx = late0 != 0u ? atomicAdd(&s_counter, 1u) : kNoClaim;
     uint32_t nxt_far = nxt_idx < tn ? far_t[nxt_idx] : 0u;
 
     // Which candidates are measured.  One that beats the best length so far agrees with the position in the four
@@ -901,12 +914,18 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                     }
                 }
                 has_pos = false;
-                if (nxt_idx >= tn) {
+                uint32_t take = nxt_idx;
+                if (take == kNoClaim) {  // the late part of the tile: claimed now, far[] from the copy in LDS
+                    take = atomicAdd(&s_counter, 1u);
+                    fd = take < tn ? s_far_late[take - late0] : 0u;
+                }
+                if (take >= tn) {
                     MDBG(if (s_t_exh == 0) s_t_exh = wall_clock64();)
                     gone = true;
+                    nxt_idx = tn;
                     ft = false;  // no positions left
                 } else {
-                    idx = nxt_idx;
+                    idx = take;
                     const uint32_t remain32 = tail_room32 - idx;  // bytes to the end of the chunk, saturated
                     cap = remain32 < max_len - 1 ? remain32 : max_len - 1;
                     best = 0;
@@ -932,7 +951,8 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
                         MDBG2(atomicAdd(&g_mdbg[4], 1ull);)
                     }
                     need_sw = false;
-                    nxt_idx = atomicAdd(&s_counter, 1u);
+                    // the next claim is held ahead only while the counter is below the late part
+                    nxt_idx = take < late0 ? atomicAdd(&s_counter, 1u) : kNoClaim;
                     const uint32_t ni = nxt_idx < tn ? nxt_idx : 0u;  // unconditional loads: tn >= 1 here
                     nxt_far = far_t[ni];
                 }
