@@ -446,22 +446,45 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 
 // lengths of one alphabet; all lanes call it, `len` and `w` live in LDS
 __device__ void wave_huff_lengths(const uint32_t *freq, int n, int max_bits, uint8_t *len, HuffWork &w, uint32_t lane) {
-    // used symbols in ascending (count, symbol) order: the rank of a symbol is the number of used symbols below it
-    uint32_t mine = 0;
-    for (int i = (int)lane; i < n; i += 64) {
-        len[i] = 0;
-        const uint32_t f = freq[i];
+    // used symbols in ascending (count, symbol) order.  They are first gathered in symbol order (count in
+    // w.weight, symbol in w.parent: both are rewritten by the merge afterwards); the rank of one is then the number
+    // of gathered entries below it, a loop over the used symbols only.
+    uint32_t mu = 0;  // uniform: entries gathered so far
+    for (int b = 0; b < n; b += 64) {
+        const int i = b + (int)lane;
+        const uint32_t f = i < n ? freq[i] : 0u;
+        if (i < n) len[i] = 0;
+        const uint64_t bal = __ballot(f != 0u);
         if (f) {
+            const uint32_t at = mu + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            w.weight[at] = f;
+            w.parent[at] = (uint16_t)i;
+        }
+        mu += (uint32_t)__popcll(bal);
+    }
+    const int m = (int)mu;
+    __syncthreads();
+    uint32_t rk[(kHuffMaxSyms + 63) / 64], sy[(kHuffMaxSyms + 63) / 64];
+#pragma unroll
+    for (int r = 0; r < (int)((kHuffMaxSyms + 63) / 64); r++) {
+        const int k = r * 64 + (int)lane;
+        rk[r] = 0;
+        sy[r] = 0;
+        if (k < m) {
+            const uint32_t f = w.weight[k];
             uint32_t rank = 0;
-            for (int j = 0; j < n; j++) {
-                const uint32_t g = freq[j];
-                rank += (g != 0u) & ((g < f) | ((g == f) & (j < i)));
+            for (int j = 0; j < m; j++) {
+                const uint32_t g = w.weight[j];
+                rank += (g < f) | ((g == f) & (j < k));
             }
-            w.sorted[rank] = (uint16_t)i;
-            mine++;
+            rk[r] = rank;
+            sy[r] = w.parent[k];
         }
     }
-    const int m = (int)wave_sum(mine);
+    __syncthreads();  // the gathered entries have been read by everybody
+#pragma unroll
+    for (int r = 0; r < (int)((kHuffMaxSyms + 63) / 64); r++)
+        if (r * 64 + (int)lane < m) w.sorted[rk[r]] = (uint16_t)sy[r];
     __syncthreads();
     if (m == 0) return;
     if (m == 1) {  // lone symbol: one bit (RFC 1951 3.2.7); the reference panics here
@@ -504,17 +527,65 @@ __device__ void wave_huff_codes(const uint8_t *len, int n, uint32_t *tab, uint32
         }
     }
     __syncthreads();
-    for (int i = (int)lane; i < n; i += 64) {
-        const uint32_t l = len[i];
-        uint32_t t = 0;
-        if (l) {
-            uint32_t rank = 0;  // symbols of the same length before this one
-            for (int j = 0; j < i; j++) rank += len[j] == l;
-            t = bit_reverse(nxt[l] + rank, l) | (l << 16);
+    uint32_t seen[17];  // uniform: symbols of each length in the groups of 64 gone by
+#pragma unroll
+    for (int L = 0; L < 17; L++) seen[L] = 0;
+    for (int b = 0; b < n; b += 64) {
+        const int i = b + (int)lane;
+        const uint32_t l = i < n ? len[i] : 0u;
+        uint32_t rank = 0;  // symbols of the same length before this one
+#pragma unroll
+        for (uint32_t L = 1; L <= 16; L++) {
+            const uint64_t bal = __ballot(l == L);
+            if (l == L) rank = seen[L] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            seen[L] += (uint32_t)__popcll(bal);
         }
-        tab[i] = t;
+        if (i < n) tab[i] = l ? (bit_reverse(nxt[l] + rank, l) | (l << 16)) : 0u;
     }
     __syncthreads();
+}
+
+// run-length items of one vector of code lengths (rle_lengths) with all lanes: every lane that stands on the
+// first element of a run codes that run (rle_run, first to count its items, then at the place a prefix sum over
+// the runs gives it).  n <= 320; returns the index behind the last item (uniform).
+__device__ int wave_rle_lengths(const uint8_t *cl, int n, uint8_t *rsym, uint8_t *rextra, int out, uint32_t lane) {
+    constexpr int kGroups = 5;
+    uint64_t starts[kGroups];
+#pragma unroll
+    for (int g = 0; g < kGroups; g++) {
+        const int i = g * 64 + (int)lane;
+        starts[g] = __ballot(i < n && (i == 0 || cl[i] != cl[i - 1]));
+    }
+#pragma unroll
+    for (int g = 0; g < kGroups; g++) {
+        const int i = g * 64 + (int)lane;
+        const bool st = (starts[g] >> lane) & 1ull;
+        int items = 0, count = 0;
+        uint8_t v = 0;
+        if (st) {
+            // the run ends where the next one starts: above this lane in the same group, else in a later group
+            int nxt_start = n;
+            const uint64_t above = lane < 63 ? starts[g] & ~((2ull << lane) - 1ull) : 0ull;
+            if (above) {
+                nxt_start = g * 64 + __ffsll((unsigned long long)above) - 1;
+            } else {
+#pragma unroll
+                for (int h = kGroups - 1; h > g; h--)
+                    if (starts[h]) nxt_start = h * 64 + __ffsll((unsigned long long)starts[h]) - 1;
+            }
+            count = nxt_start - i;
+            v = cl[i];
+            items = rle_run<false>(v, count, rsym, rextra, 0);
+        }
+        uint32_t incl = (uint32_t)items;  // inclusive scan over the wave
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += o;
+        }
+        if (st) rle_run<true>(v, count, rsym, rextra, out + (int)incl - items);
+        out += (int)__shfl(incl, 63);
+    }
+    return out;
 }
 
 __device__ uint32_t build_block_wave(const uint32_t *freq_ll, const uint32_t *freq_d, int strategy, bool bfinal,
@@ -550,13 +621,9 @@ __device__ uint32_t build_block_wave(const uint32_t *freq_ll, const uint32_t *fr
         const int dmax = wave_max(dany) ? (int)wave_max(dm) : 1;
         const int nl = lmax + 1, nd = dmax + 1;
         if (lane < 19) hw.cl_freq[lane] = 0;
-        if (lane == 0) {
-            int nr = rle_lengths(hw.ll_len, nl, hw.rsym, hw.rextra, 0);  // the two vectors are coded separately
-            nr = rle_lengths(hw.d_len, nd, hw.rsym, hw.rextra, nr);
-            shared2[0] = (uint32_t)nr;
-        }
+        int nr = wave_rle_lengths(hw.ll_len, nl, hw.rsym, hw.rextra, 0, lane);  // the two vectors are coded separately
+        nr = wave_rle_lengths(hw.d_len, nd, hw.rsym, hw.rextra, nr, lane);
         __syncthreads();
-        const int nr = (int)shared2[0];
         for (int i = (int)lane; i < nr; i += 64) atomicAdd(&hw.cl_freq[hw.rsym[i]], 1u);
         __syncthreads();
         if (lane == 0) {

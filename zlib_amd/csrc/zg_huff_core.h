@@ -243,8 +243,53 @@ struct HeaderWork {
     HuffWork hw;
 };
 
-// code-length run-length coding of one vector (run_length_encode + rle_to_zlib_codes,
-// src/compress.rs:472-569)
+// code-length run-length coding (run_length_encode + rle_to_zlib_codes, src/compress.rs:472-569).
+// One run of `count` equal values v: its items go to rsym / rextra from index `out` on (kEmit) or are only
+// counted; returns the index behind them.
+template <bool kEmit>
+ZG_HD inline int rle_run(uint8_t v, int count, uint8_t *rsym, uint8_t *rextra, int out) {
+    auto item = [&](uint8_t sym, uint8_t extra) {
+        if (kEmit) {
+            rsym[out] = sym;
+            rextra[out] = extra;
+        }
+        out++;
+    };
+    if (count == 1) {  // Once(v)
+        item(v, 0);
+    } else if (v == 0) {  // zlib_rle_encode_zero
+        int rep = count;
+        while (rep > 0) {
+            if (rep >= 3 && rep <= 10) {
+                item(17, (uint8_t)rep);
+                break;
+            } else if (rep >= 11) {
+                const int cur = rep > 138 ? 138 : rep;
+                rep -= cur;
+                item(18, (uint8_t)cur);
+            } else {
+                for (int i = 0; i < rep; i++) item(0, 0);
+                break;
+            }
+        }
+    } else {  // zlib_rle_encode_nonzero: the value itself, then a repeat of up to 6, and again
+        int rep = count;
+        while (rep > 0) {
+            if (rep <= 3) {
+                for (int i = 0; i < rep; i++) item(v, 0);
+                break;
+            }
+            item(v, 0);
+            rep -= 1;
+            const int cur = rep > 6 ? 6 : rep;
+            rep -= cur;
+            item(16, (uint8_t)cur);
+        }
+    }
+    return out;
+}
+
+// one vector, run by run
 ZG_HD inline int rle_lengths(const uint8_t *cl, int n, uint8_t *rsym, uint8_t *rextra, int out) {
     int pos = 0;
     while (pos < n) {
@@ -252,48 +297,7 @@ ZG_HD inline int rle_lengths(const uint8_t *cl, int n, uint8_t *rsym, uint8_t *r
         int count = 1;
         while (pos + count < n && cl[pos + count] == v) count++;
         pos += count;
-        if (count == 1) {  // Once(v)
-            rsym[out] = v;
-            rextra[out++] = 0;
-        } else if (v == 0) {  // zlib_rle_encode_zero
-            int rep = count;
-            while (rep > 0) {
-                if (rep >= 3 && rep <= 10) {
-                    rsym[out] = 17;
-                    rextra[out++] = (uint8_t)rep;
-                    break;
-                } else if (rep >= 11) {
-                    const int cur = rep > 138 ? 138 : rep;
-                    rep -= cur;
-                    rsym[out] = 18;
-                    rextra[out++] = (uint8_t)cur;
-                } else {
-                    for (int i = 0; i < rep; i++) {
-                        rsym[out] = 0;
-                        rextra[out++] = 0;
-                    }
-                    break;
-                }
-            }
-        } else {  // zlib_rle_encode_nonzero: the value itself, then a repeat of up to 6, and again
-            int rep = count;
-            while (rep > 0) {
-                if (rep <= 3) {
-                    for (int i = 0; i < rep; i++) {
-                        rsym[out] = v;
-                        rextra[out++] = 0;
-                    }
-                    break;
-                }
-                rsym[out] = v;
-                rextra[out++] = 0;
-                rep -= 1;
-                const int cur = rep > 6 ? 6 : rep;
-                rep -= cur;
-                rsym[out] = 16;
-                rextra[out++] = (uint8_t)cur;
-            }
-        }
+        out = rle_run<true>(v, count, rsym, rextra, out);
     }
     return out;
 }
