@@ -626,9 +626,9 @@ __device__ uint32_t build_block_wave(const uint32_t *freq_ll, const uint32_t *fr
         __syncthreads();
         for (int i = (int)lane; i < nr; i += 64) atomicAdd(&hw.cl_freq[hw.rsym[i]], 1u);
         __syncthreads();
+        wave_huff_lengths(hw.cl_freq, 19, 7, hw.cl_len, hw.hw, lane);  // get_code_tree
+        wave_huff_codes(hw.cl_len, 19, hw.cl_tab, cnt, nxt, lane);
         if (lane == 0) {
-            huff_lengths(hw.cl_freq, 19, 7, hw.cl_len, hw.hw);  // get_code_tree
-            huff_codes(hw.cl_len, 19, hw.cl_tab);
             const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
             int nh = 19;  // get_hcodes: trailing zeros trimmed
             while (nh > 4 && hw.cl_len[order[nh - 1]] == 0) nh--;
