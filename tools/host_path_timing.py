@@ -14,3 +14,16 @@ for rep in range(3):
     print(f"host in / host out: {n / dt / 1e9:.2f} GB/s ({dt * 1e3:.0f} ms), ratio {len(out) / n:.4f}", flush=True)
 ok = zlib.decompress(out) == data
 print("round trip", ok)
+# the stream front end: the same bytes pulled from / pushed to files (segments of 256 MiB, three threads)
+import tempfile
+with tempfile.TemporaryDirectory() as td:
+    src, dst = os.path.join(td, "in.bin"), os.path.join(td, "out.z")
+    with open(src, "wb") as f:
+        f.write(data)
+    for rep in range(2):
+        t0 = time.perf_counter()
+        n_in, n_out = za.compress_file(src, dst, za.Strategy.Dynamic)
+        dt = time.perf_counter() - t0
+        print(f"file to file: {n_in / dt / 1e9:.2f} GB/s ({dt * 1e3:.0f} ms)", flush=True)
+    with open(dst, "rb") as f:
+        print("file stream equals the in-memory one", f.read() == out)

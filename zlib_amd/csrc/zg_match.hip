@@ -592,7 +592,7 @@ uint64_t index_lookback(uint32_t window) { return window; }
 // ---------------------------------------------------------------------------
 
 template <class G>
-__global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict__ data, uint64_t first,
+__global__ __launch_bounds__(G::match_threads) void k_match(const uint8_t *__restrict__ data, uint64_t first,
                                                           uint64_t end, uint64_t chunk_bytes,
                                                           const uint32_t *__restrict__ clen, uint32_t isolated,
                                                           uint32_t c0, uint32_t tiles_per_chunk, MatchParams mp,
@@ -644,8 +644,8 @@ __global__ __launch_bounds__(G::threads) void k_match(const uint8_t *__restrict_
          if (tid == 0) s_t_exh = 0;)
 
     const uint32_t late0 = (uint32_t)(t1 - t0) > kLate ? (uint32_t)(t1 - t0) - kLate : 0u;
-    for (uint32_t i = tid; late0 + i < (uint32_t)(t1 - t0); i += G::threads) s_far_late[i] = far[(t0 - base) + late0 + i];
-    stage_tile(data, next, base, w0, nbytes, nlinks, s_data, s_next, tid, G::threads, G::data_lds);
+    for (uint32_t i = tid; late0 + i < (uint32_t)(t1 - t0); i += G::match_threads) s_far_late[i] = far[(t0 - base) + late0 + i];
+    stage_tile(data, next, base, w0, nbytes, nlinks, s_data, s_next, tid, G::match_threads, G::data_lds);
     __syncthreads();
     MDBG(const unsigned long long t_staged = wall_clock64();)
 
@@ -1354,11 +1354,11 @@ hipError_t launch_match(const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchParam
     const uint32_t tpc = match_tiles_per_chunk(g);
     const uint64_t nblocks = (uint64_t)(c1 - c0) * tpc;
     if (match_tile_positions(g) == kMatchRecordTile)
-        hipLaunchKernelGGL(k_match<GeomRecord>, dim3((uint32_t)nblocks), dim3(GeomRecord::threads), 0, s, g.data,
+        hipLaunchKernelGGL(k_match<GeomRecord>, dim3((uint32_t)nblocks), dim3(GeomRecord::match_threads), 0, s, g.data,
                            g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, rec_min,
                            open_list ? 1u : 0u, far, next, base, match, open_list, open_cnt, walk_chunk);
     else
-        hipLaunchKernelGGL(k_match<GeomStream>, dim3((uint32_t)nblocks), dim3(GeomStream::threads), 0, s, g.data,
+        hipLaunchKernelGGL(k_match<GeomStream>, dim3((uint32_t)nblocks), dim3(GeomStream::match_threads), 0, s, g.data,
                            g.first, g.end, g.chunk_bytes, g.chunk_len, g.isolated, c0, tpc, mp, rec_min,
                            open_list ? 1u : 0u, far, next, base, match, open_list, open_cnt, walk_chunk);
     return hipGetLastError();

@@ -20,6 +20,9 @@ __device__ __forceinline__ uint32_t xcd_tile_index(uint32_t b, uint32_t n) {
 // Geometry of a match workgroup: positions per tile, positions of window staged before them, threads, and how
 // many parked level-2 walks it can hold.  GeomStream is the general one; GeomRecord serves isolated chunks (records) of at most 4 KiB, whose window is
 // the record itself -- a twelfth of the LDS, so that many records are resident per CU.
+#ifndef ZG_MATCH_STREAM_THREADS
+#define ZG_MATCH_STREAM_THREADS 1024
+#endif
 #ifndef ZG_LO_STREAM_THREADS
 #define ZG_LO_STREAM_THREADS 1024
 #endif
@@ -27,6 +30,7 @@ template <uint32_t kTileT, uint32_t kWinT, uint32_t kThreadsT, uint32_t kParkedT
 struct MatchGeom {
     static constexpr uint32_t tile = kTileT, win = kWinT, threads = kThreadsT, parked = kParkedT;
     static constexpr uint32_t lo_threads = kThreadsT == 1024 ? ZG_LO_STREAM_THREADS : kThreadsT;  // level 2
+    static constexpr uint32_t match_threads = kThreadsT == 1024 ? ZG_MATCH_STREAM_THREADS : kThreadsT;  // level 1
     static constexpr uint32_t data_lds = kWinT + kTileT + 16 + 272;  // 16: alignment slack, 272: look-ahead + pad
     static constexpr uint32_t next_lds = kWinT + kTileT + 16;
 };
