@@ -29,16 +29,16 @@
 #include <type_traits>
 
 #ifndef ZG_MATCH_STEPS
-#define ZG_MATCH_STEPS 12
+#define ZG_MATCH_STEPS 9
 #endif
 #ifndef ZG_MATCH_STEPS_REC
 #define ZG_MATCH_STEPS_REC 8
 #endif
 #ifndef ZG_MATCH_COOP_LANES
-#define ZG_MATCH_COOP_LANES 2  // a draining wave with at most this many walking lanes finishes long walks together; 0: never
+#define ZG_MATCH_COOP_LANES 4  // a draining wave with at most this many walking lanes finishes long walks together; 0: never
 #endif
 #ifndef ZG_MATCH_COOP_GAIN
-#define ZG_MATCH_COOP_GAIN 8   // ... by this factor (the comparison stalls the wave's other walks and measures every true candidate)
+#define ZG_MATCH_COOP_GAIN 4   // ... by this factor (the comparison stalls the wave's other walks and measures every true candidate)
 #endif
 #ifndef ZG_MATCH_COOP_BASE
 #define ZG_MATCH_COOP_BASE 3   // ... those expected to take more than this many trips plus one per 2 KiB left
@@ -688,7 +688,10 @@ __global__ __launch_bounds__(G::match_threads) void k_match(const uint8_t *__res
 #define ZG_SWITCH_GAIN4 8  // quarters: the new chain's links must be this many times as long
 #endif
 #ifndef ZG_SWITCH_TRIPS
-#define ZG_SWITCH_TRIPS 2
+#define ZG_SWITCH_TRIPS 1
+#endif
+#ifndef ZG_SWITCH_TRIPS_REC
+#define ZG_SWITCH_TRIPS_REC 2  // inside a record
 #endif
 #ifndef ZG_SWITCH_EVERY
 #define ZG_SWITCH_EVERY 4
@@ -700,7 +703,8 @@ __global__ __launch_bounds__(G::match_threads) void k_match(const uint8_t *__res
 #define ZG_SWITCH_BATCH 4
 #endif
     // a walk may change chains after kSwitchTrips trips (0: never), once kSwitchBatch lanes want to
-    constexpr uint32_t kSwitchTrips = ZG_SWITCH_TRIPS, kSwitchBatch = ZG_SWITCH_BATCH, kSwitchRemain = ZG_SWITCH_REMAIN;
+    constexpr uint32_t kSwitchTrips = G::tile == kMatchRecordTile ? ZG_SWITCH_TRIPS_REC : ZG_SWITCH_TRIPS;
+    constexpr uint32_t kSwitchBatch = ZG_SWITCH_BATCH, kSwitchRemain = ZG_SWITCH_REMAIN;
     // what a lane is doing: walking (hd), waiting to have a candidate measured (ev), waiting to retire its
     // position and claim another (ft), or none of them (no positions left).  Kept as predicates, so that the
     // bookkeeping of a head step is scalar mask arithmetic.
