@@ -273,12 +273,20 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_li
     uint16_t *next_seg = next + (a0 - base);
     bool violated = false;
 
+    // (offsets are taken from a base at or below every clamped offset, so that they are unsigned 32-bit values:
+    // a scalar base plus a vector offset, without the 64-bit address arithmetic of a signed index)
+    auto st16 = [](uint16_t *base_p, uint32_t i, uint32_t v) {  // base_p[i] = v with a 32-bit byte offset (i < 2^31)
+        *reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(base_p) + (i << 1)) = (uint16_t)v;
+    };
+    const int32_t low = last < 0 ? last : 0;
+    const uint8_t *dlow = dseg + low;
     auto raw_at = [&](uint32_t q) -> RawKey<K> {  // branch-free: the offset is clamped into the view
         const int32_t qc = (int32_t)q < last ? (int32_t)q : last;
+        const uint32_t off = (uint32_t)(qc - low);
         RawKey<K> r;
-        __builtin_memcpy(&r.a, dseg + qc, 4);
+        __builtin_memcpy(&r.a, dlow + off, 4);
         r.b = 0;
-        if (K > 4) __builtin_memcpy(&r.b, dseg + qc + 4, 4);
+        if (K > 4) __builtin_memcpy(&r.b, dlow + off + 4u, 4);
         return r;
     };
     auto hash_of = [&](RawKey<K> r, uint32_t q, bool exact) -> uint32_t {
@@ -356,7 +364,7 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_li
             if (kNext) {
                 // a link counts within the window and within the slot
                 const uint32_t nd = (d <= window && old1[k] - 1u < slot_end) ? d : 0u;
-                if (kNext == 1 || (qi >= q_a && qi < q_b)) next_seg[qi] = (uint16_t)nd;
+                if (kNext == 1 || (qi >= q_a && qi < q_b)) st16(next_seg, qi, nd);
             }
             if (kLook) {
                 s_link[qi - qg] = d;
@@ -389,7 +397,7 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_li
             for (int k = 0; k < (int)kIdxGroup; k++) {
                 const uint32_t ql = look_pos(qg, k);
                 if (kLook == 1 || (ql >= q_far && ql < q_b && ql < slot_end))
-                    far_seg[ql] = (uint16_t)(lv[k] ? ql - e[k] : 0u);
+                    st16(far_seg, ql, lv[k] ? ql - e[k] : 0u);
             }
         }
         if (sweep) {
@@ -405,7 +413,7 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_li
                 for (int j = 0; j < (int)kIdxGroup; j++) {
                     const uint32_t p = pb + (uint32_t)j * 64 + lane;
                     const uint32_t m1 = s_head[hash_of(r[j], p, false)];
-                    if (p >= q_far && p < pe) far_seg[p] = (uint16_t)((p + K <= n_rel && m1) ? p + 1u - m1 : 0u);
+                    if (p >= q_far && p < pe) st16(far_seg, p, (p + K <= n_rel && m1) ? p + 1u - m1 : 0u);
                 }
             }
         }
