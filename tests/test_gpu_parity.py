@@ -244,6 +244,40 @@ def test_streams_small(za, z, strategy):
             assert sysz.decompress(got) == data
 
 
+def test_auto_reaches_every_branch_of_the_heuristic(za, z):
+    """Strategy::Auto (src/compress.rs:89-169): below 256 bytes stored blocks, below 1 KiB the fixed code, from there
+    on the first KiB decides -- entropy against log2 of its alphabet (:125-138), the share of its five RAREST symbols
+    (:140-150, sorted ascending), and, when the two cancel, symbols x log2(len) / len (:157-167).  One input per
+    branch and threshold; the expected block type is what the restated heuristic yields, the stream must equal the
+    oracle's Auto stream and that strategy's own stream."""
+    rng = random.Random(2026)
+    text = za.corpus("text", 6000)
+    skew = bytes(rng.choice(b"a" * 99 + b"b") for _ in range(4000))
+    dominant = bytearray(b"a" * 1024)  # one symbol and 51 single ones: proximity 0.1, the third rule decides
+    for i in range(51):
+        dominant[17 * i + 3] = 100 + i
+    cases = [
+        (bytes(rng.randrange(256) for _ in range(255)), "Raw"),       # :91
+        (bytes(rng.randrange(256) for _ in range(256)), "Fixed"),     # :97
+        (text[:1023], "Fixed"),
+        (text[:1024], "Fixed"),                                         # entropy close to log2(alphabet): :152
+        (text, "Fixed"),
+        (bytes(rng.randrange(256) for _ in range(5000)), "Fixed"),
+        (skew[:3000], "Dynamic"),                                       # five symbols hold everything: :154
+        (bytes(rng.choice(b"ab") for _ in range(3000)), "Dynamic"),   # the two cancel, ratio 0.008: :163
+        (bytes(3000), "Dynamic"),                                       # one symbol: 0 / 0, every comparison false
+        (bytes(dominant) + b"a" * 16, "Fixed"),                         # the two cancel, 52 * log2(1040) / 1040 > 0.5: :165
+        (bytes(dominant) + b"a" * 176, "Dynamic"),                      # ... 52 * log2(1200) / 1200 < 0.5
+        (bytes(rng.randrange(256) for _ in range(1024)) + text[:3000], "Fixed"),   # only the first KiB is looked at
+        (skew[:1024] + bytes(rng.randrange(256) for _ in range(3000)), "Dynamic"),
+    ]
+    for data, want in cases:
+        got = za.compress(data, za.Strategy.Auto)
+        _same(got, z.compress_chunked(data, z.AUTO, 1 << 20, fast=True), (len(data), want))
+        _same(got, za.compress(data, getattr(za.Strategy, want)), (len(data), want))
+        assert sysz.decompress(got) == data
+
+
 @pytest.mark.parametrize("strategy", ["Dynamic", "Fixed"])
 def test_streams_equal_reference_single_chunk(za, z, strategy):
     """n <= chunk_bytes: the stream is the reference crate's stream byte for byte."""
