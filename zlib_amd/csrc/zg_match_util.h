@@ -35,7 +35,10 @@ struct MatchGeom {
     static constexpr uint32_t next_lds = kWinT + kTileT + 16;
 };
 using GeomStream = MatchGeom<kMatchTile, kMaxWindow, kMatchThreads, 1024>;
-using GeomRecord = MatchGeom<kMatchRecordTile, 0, 256, 64>;
+#ifndef ZG_RECORD_THREADS
+#define ZG_RECORD_THREADS 256
+#endif
+using GeomRecord = MatchGeom<kMatchRecordTile, 0, ZG_RECORD_THREADS, 64>;
 
 // four bytes at an arbitrary LDS byte offset, from two aligned dwords.  gfx950 also reads an LDS dword at any
 // alignment with one ds_read_b32 (tools/probe/probe_lds_unaligned.hip: correct for every offset), but far more
