@@ -1042,6 +1042,9 @@ constexpr uint32_t kOpenAgain = 0x80000000u;  // list entry: four-byte chain exh
 #ifndef ZG_LO_BUDGET
 #define ZG_LO_BUDGET 64
 #endif
+#ifndef ZG_LO_THREE_FIRST
+#define ZG_LO_THREE_FIRST 1  // tiles with nine positions in ten open: three-byte pass before the four-byte pass; 0: never
+#endif
 
 // One pass of level 2 over a tile's list.  Walk lengths are very uneven (a rare key that shares its bucket with
 // a frequent one walks through all of the latter's members), so, as in level 1, lanes claim list entries from
@@ -1063,7 +1066,16 @@ extern "C" int zg_debug_counters(unsigned long long *out) {
 #ifdef ZG_DEBUG_PHASES
 __device__ long long g_t0[4096];
 #endif
-template <int kPass, uint32_t kParked, uint32_t kThreads>
+// kMode 0: the usual order (four-byte pass over every entry, three-byte pass over the entries it marks).
+// kMode 1: the other order, for tiles in which level 1 left almost every position open (incompressible data: a
+//          position there has a three-byte candidate once in five hundred, a four-byte one next to never, yet each
+//          pass walks its four colliding bucket members): the three-byte pass runs FIRST, over every entry, records
+//          what it finds and marks the entry; the four-byte pass then looks at the marked entries only and, where it
+//          finds a candidate, overrides the record.  The same answers: a candidate agreeing in four bytes agrees in
+//          three, so an entry without a three-byte candidate has no four-byte one; four bytes beat three at any
+//          distance; and a search the three-byte pass sees ended (distance <= length + 1) has no four-byte candidate
+//          beyond distance five, for that one would have been the farther three-byte candidate.
+template <int kPass, int kMode, uint32_t kParked, uint32_t kThreads>
 __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s_next, uint32_t *s_counter,
                                         uint32_t *s_nparked, uint32_t *s_park, uint32_t *open_t,
                                         const uint32_t *far_t, uint32_t n_open, uint32_t *match_t, uint32_t pbase,
@@ -1139,10 +1151,12 @@ __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s
                 uint32_t ex = nxt_e, ef = nxt_f;
                 asm volatile("" : "+v"(ex), "+v"(ef));
                 if (has_pos) {
-                    if (res)
+                    if (res) {
                         match_t[idx] = res;
-                    else if (kPass == 1)
+                        if (kMode == 1 && kPass == 2) open_t[cur_i] = cur_e | kOpenAgain;  // the four-byte pass has a look
+                    } else if (kMode == 0 && kPass == 1) {
                         open_t[cur_i] = cur_e | kOpenAgain;
+                    }
                 }
                 has_pos = false;
                 if (nxt_i >= n_open) {
@@ -1158,7 +1172,7 @@ __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s
                     res = 0;
                     trips = 0;
                     // the reference searches only while pos < len - min_len, and records nothing below min_len
-                    const bool valid = remain32 > min_len && lim >= min_len && (kPass == 1 || (ex & kOpenAgain));
+                    const bool valid = remain32 > min_len && lim >= min_len && ((kMode == 0 ? kPass == 1 : kPass == 2) || (ex & kOpenAgain));
                     const uint32_t fd = kPass == 1 ? (lim >= 4u ? (ef & 0xFFFFu) : 0u) : (ef >> 16);
                     has_pos = valid;
 #ifdef ZG_DEBUG_COUNTERS
@@ -1239,7 +1253,7 @@ __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s
             if (kPass == 1) {
                 if (hit != 0xFFFFFFFFu)
                     match_t[pidx] = (4u << 16) | (ppo - hit);
-                else
+                else if (kMode == 0)
                     open_t[pi] = pe | kOpenAgain;
             } else if (hit != 0xFFFFFFFFu) {
                 const uint32_t remain32 = tail_room32 - pidx;
@@ -1249,7 +1263,10 @@ __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s
                 uint32_t m = hit_x ? ((uint32_t)__builtin_ctz(hit_x) >> 3) : 4u;
                 m = m < plim ? m : plim;
                 const uint32_t d = ppo - hit;
-                if (d > m + 1u) match_t[pidx] = (m << 16) | d;  // else the growing match reaches pos
+                if (d > m + 1u) {  // else the growing match reaches pos
+                    match_t[pidx] = (m << 16) | d;
+                    if (kMode == 1) open_t[pi] = pe | kOpenAgain;
+                }
             }
         }
     }
@@ -1309,7 +1326,12 @@ __global__ __launch_bounds__(G::lo_threads) void k_match_lo(const uint8_t *__res
 #ifdef ZG_DEBUG_PHASES
     if (tid == 0) g_t0[blockIdx.x & 4095] = clock64();
 #endif
-    stage_tile(data, next4, base, w0, nbytes, nlinks, s_data, s_next, tid, G::lo_threads, G::data_lds);
+    const uint32_t pbase = (uint32_t)(t0 - w0);
+    const uint64_t tail_room = ce - t0;
+    const uint32_t tail_room32 = tail_room < 0x7FFFFFFFull ? (uint32_t)tail_room : 0x7FFFFFFFu;
+    // almost every position of the tile open: the three-byte pass first (see lo_pass)
+    const bool three_first = ZG_LO_THREE_FIRST != 0 && mp.min_len == 3u && (uint64_t)n_open * 10u >= (t1 - t0) * 9u;
+    stage_tile(data, three_first ? next3 : next4, base, w0, nbytes, nlinks, s_data, s_next, tid, G::lo_threads, G::data_lds);
     __syncthreads();
 #ifdef ZG_DEBUG_PHASES
     if (tid == 0) {
@@ -1320,13 +1342,13 @@ __global__ __launch_bounds__(G::lo_threads) void k_match_lo(const uint8_t *__res
     }
     __syncthreads();
 #endif
-
-    const uint32_t pbase = (uint32_t)(t0 - w0);
-    const uint64_t tail_room = ce - t0;
-    const uint32_t tail_room32 = tail_room < 0x7FFFFFFFull ? (uint32_t)tail_room : 0x7FFFFFFFu;
-    lo_pass<1, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open, match_t,
-                                      pbase, tail_room32, mp.min_len, mp.max_len);
-    __syncthreads();  // also orders the list entries written in pass 1 before their readers in pass 2
+    if (three_first)
+        lo_pass<2, 1, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open,
+                                                match_t, pbase, tail_room32, mp.min_len, mp.max_len);
+    else
+        lo_pass<1, 0, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open,
+                                                match_t, pbase, tail_room32, mp.min_len, mp.max_len);
+    __syncthreads();  // also orders the list entries written in the first pass before their readers in the second
 #ifdef ZG_DEBUG_PHASES
     if (tid == 0) {
         atomicAdd(&g_dbg[3], (unsigned long long)(clock64() - g_t0[blockIdx.x & 4095]));
@@ -1339,7 +1361,7 @@ __global__ __launch_bounds__(G::lo_threads) void k_match_lo(const uint8_t *__res
         s_counter = 0;
         s_nparked = 0;
     }
-    stage_links(next3, base, w0, nlinks, s_next, tid, G::lo_threads);
+    stage_links(three_first ? next4 : next3, base, w0, nlinks, s_next, tid, G::lo_threads);
     __syncthreads();
 #ifdef ZG_DEBUG_PHASES
     if (tid == 0) {
@@ -1348,8 +1370,12 @@ __global__ __launch_bounds__(G::lo_threads) void k_match_lo(const uint8_t *__res
     }
     __syncthreads();
 #endif
-    lo_pass<2, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open, match_t,
-                                      pbase, tail_room32, mp.min_len, mp.max_len);
+    if (three_first)
+        lo_pass<1, 1, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open,
+                                                match_t, pbase, tail_room32, mp.min_len, mp.max_len);
+    else
+        lo_pass<2, 0, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open,
+                                                match_t, pbase, tail_room32, mp.min_len, mp.max_len);
 #ifdef ZG_DEBUG_PHASES
     __syncthreads();
     if (tid == 0) {
