@@ -313,6 +313,28 @@ def test_long_runs_and_periodic_data(za, z):
             assert sysz.decompress(got) == data
 
 
+def test_mostly_incompressible_tiles_with_sparse_repeats(za, z):
+    """Random bytes with a few short strings sprinkled in: level 1 leaves nearly every position open, so level 2 takes
+    the three-byte chains first and looks for four-byte candidates along them; the sprinkled strings recur often
+    enough for their chains to outrun a walk's budget (parked scans, the four-byte pass after all), at distances
+    around the limits of five and of the strings' own lengths."""
+    rng = random.Random(515)
+    marks = [b"ABCD", b"XYZ", b"QRSTU", b"ABCE", b"XYZW"]
+    for n, gap in ((300_000, 150), (200_000, 40), (120_000, 9)):
+        out = bytearray()
+        while len(out) < n:
+            out += bytes(rng.randrange(256) for _ in range(rng.randint(1, 2 * gap)))
+            out += rng.choice(marks)
+            if rng.random() < 0.1:
+                out += rng.choice(marks)  # back to back: distances of three to five
+        data = bytes(out[:n])
+        _same(za.zlib_compressor().compress_packed(data), z.lz77_zlib(data, fast=True), (n, gap))
+        for chunk in (1 << 20, 65536):
+            got = za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk)
+            _same(got, z.compress_chunked(data, z.DYNAMIC, chunk, fast=True), (n, gap, chunk))
+            assert sysz.decompress(got) == data
+
+
 @pytest.mark.gpu
 def test_motif_soup_long_chains_with_periodic_neighbourhoods(za, z):
     """Few symbols, short motifs repeated a random number of times: five-byte chains thousands of members long,

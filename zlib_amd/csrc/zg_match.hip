@@ -1067,7 +1067,7 @@ extern "C" int zg_debug_counters(unsigned long long *out) {
 __device__ long long g_t0[4096];
 #endif
 // kMode 0: the usual order (four-byte pass over every entry, three-byte pass over the entries it marks).
-// kMode 1: the other order, for tiles in which level 1 left almost every position open (incompressible data: a
+// kMode 2, 1: the other order, for tiles in which level 1 left almost every position open (incompressible data: a
 //          position there has a three-byte candidate once in five hundred, a four-byte one next to never, yet each
 //          pass walks its four colliding bucket members): the three-byte pass runs FIRST, over every entry, records
 //          what it finds and marks the entry; the four-byte pass then looks at the marked entries only and, where it
@@ -1075,9 +1075,13 @@ __device__ long long g_t0[4096];
 //          three, so an entry without a three-byte candidate has no four-byte one; four bytes beat three at any
 //          distance; and a search the three-byte pass sees ended (distance <= length + 1) has no four-byte candidate
 //          beyond distance five, for that one would have been the farther three-byte candidate.
+//          The three-byte pass of that order (kMode 2) goes on along its chain after its first candidate, which
+//          holds the four-byte candidates as well, and takes the first of those beyond distance five; only an
+//          entry whose walk runs out of budget is left to a four-byte pass (kMode 1: marked entries only), and a
+//          tile without such an entry is done after one pass.
 template <int kPass, int kMode, uint32_t kParked, uint32_t kThreads>
 __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s_next, uint32_t *s_counter,
-                                        uint32_t *s_nparked, uint32_t *s_park, uint32_t *open_t,
+                                        uint32_t *s_nparked, uint32_t *s_park, uint32_t *s_second, uint32_t *open_t,
                                         const uint32_t *far_t, uint32_t n_open, uint32_t *match_t, uint32_t pbase,
                                         uint32_t tail_room32, uint32_t min_len, uint32_t max_len) {
     constexpr int kSteps = ZG_LO_STEPS;
@@ -1107,6 +1111,17 @@ __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s
                 const bool hit = w == p0;
                 res = (hd & !stop_pre & hit) ? ((4u << 16) | d) : res;
                 fin = hd & (stop_pre | hit | (nx == 0u));
+            } else if (kMode == 2) {
+                const uint32_t x = w ^ p0;
+                uint32_t m = ((uint32_t)__ffs((int)x) - 1u) >> 3;  // equal leading bytes; huge when all four agree
+                m = m < lim ? m : lim;
+                const bool live = hd & !stop_pre;
+                const bool first = live & (m >= min_len) & (res == 0u);  // the farthest candidate of three bytes or four
+                const bool ends = d <= m + 1u;                            // ... reached by its growing match: search over
+                const bool four = live & (x == 0u) & (lim >= 4u) & (d > 5u);  // four bytes beyond distance five: the answer
+                res = (first & !ends) ? ((m << 16) | d) : res;
+                res = four ? ((4u << 16) | d) : res;
+                fin = hd & (stop_pre | (first & ends) | four | (nx == 0u));
             } else {
                 const uint32_t x = w ^ p0;
                 uint32_t m = ((uint32_t)__ffs((int)x) - 1u) >> 3;  // equal leading bytes; huge when all four agree
@@ -1124,6 +1139,15 @@ __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s
             hd &= !fin;
         }
         trips += 1;
+        if (kMode == 2 && hd && trips >= kBudgetTrips && res != 0u) {
+            // a three-byte candidate is recorded, the four-byte one is left to a pass over the four-byte chains
+            match_t[idx] = res;
+            open_t[cur_i] = cur_e | kOpenAgain;
+            *s_second = 1u;
+            hd = false;
+            ft = true;
+            has_pos = false;
+        }
         if (hd && trips >= kBudgetTrips) {
             const uint32_t slot = atomicAdd(s_nparked, 1u);
             if (slot < kParked) {
@@ -1265,7 +1289,7 @@ __device__ __forceinline__ void lo_pass(const uint8_t *s_data, const uint16_t *s
                 const uint32_t d = ppo - hit;
                 if (d > m + 1u) {  // else the growing match reaches pos
                     match_t[pidx] = (m << 16) | d;
-                    if (kMode == 1) open_t[pi] = pe | kOpenAgain;
+                    if (kMode != 0) open_t[pi] = pe | kOpenAgain;
                 }
             }
         }
@@ -1289,6 +1313,7 @@ __global__ __launch_bounds__(G::lo_threads) void k_match_lo(const uint8_t *__res
     __shared__ uint32_t s_park[G::parked * 2];  // list index, cursor
     __shared__ uint32_t s_counter;              // next unclaimed list entry
     __shared__ uint32_t s_nparked;
+    __shared__ uint32_t s_second;               // three-byte pass first: an entry needs the four-byte pass after all
     uint8_t *const s_data = s_mem;
     uint16_t *const s_next = reinterpret_cast<uint16_t *>(s_mem + G::data_lds);
 
@@ -1314,6 +1339,7 @@ __global__ __launch_bounds__(G::lo_threads) void k_match_lo(const uint8_t *__res
     if (tid == 0) {
         s_counter = 0;
         s_nparked = 0;
+        s_second = 0;
     }
     // the chain entries of the listed positions, beside the list: far4 | far3 << 16
     {
@@ -1343,12 +1369,15 @@ __global__ __launch_bounds__(G::lo_threads) void k_match_lo(const uint8_t *__res
     __syncthreads();
 #endif
     if (three_first)
-        lo_pass<2, 1, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open,
-                                                match_t, pbase, tail_room32, mp.min_len, mp.max_len);
+        lo_pass<2, 2, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, &s_second, open_t, far_t,
+                                                n_open, match_t, pbase, tail_room32, mp.min_len, mp.max_len);
     else
-        lo_pass<1, 0, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open,
-                                                match_t, pbase, tail_room32, mp.min_len, mp.max_len);
+        lo_pass<1, 0, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, &s_second, open_t, far_t,
+                                                n_open, match_t, pbase, tail_room32, mp.min_len, mp.max_len);
     __syncthreads();  // also orders the list entries written in the first pass before their readers in the second
+    // the three-byte pass first, and every walk stayed within its budget: all answers are there
+    if (three_first && s_second == 0u && s_nparked == 0u) return;
+    __syncthreads();  // (the counters are read before they are cleared)
 #ifdef ZG_DEBUG_PHASES
     if (tid == 0) {
         atomicAdd(&g_dbg[3], (unsigned long long)(clock64() - g_t0[blockIdx.x & 4095]));
@@ -1371,11 +1400,11 @@ __global__ __launch_bounds__(G::lo_threads) void k_match_lo(const uint8_t *__res
     __syncthreads();
 #endif
     if (three_first)
-        lo_pass<1, 1, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open,
-                                                match_t, pbase, tail_room32, mp.min_len, mp.max_len);
+        lo_pass<1, 1, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, &s_second, open_t, far_t,
+                                                n_open, match_t, pbase, tail_room32, mp.min_len, mp.max_len);
     else
-        lo_pass<2, 0, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, open_t, far_t, n_open,
-                                                match_t, pbase, tail_room32, mp.min_len, mp.max_len);
+        lo_pass<2, 0, G::parked, G::lo_threads>(s_data, s_next, &s_counter, &s_nparked, s_park, &s_second, open_t, far_t,
+                                                n_open, match_t, pbase, tail_room32, mp.min_len, mp.max_len);
 #ifdef ZG_DEBUG_PHASES
     __syncthreads();
     if (tid == 0) {
