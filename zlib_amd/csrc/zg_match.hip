@@ -1042,6 +1042,9 @@ constexpr uint32_t kOpenAgain = 0x80000000u;  // list entry: four-byte chain exh
 #ifndef ZG_LO_BUDGET
 #define ZG_LO_BUDGET 64
 #endif
+#ifndef ZG_LO_THREE_FIRST_TENTHS
+#define ZG_LO_THREE_FIRST_TENTHS 9  // ... this many positions in ten open
+#endif
 #ifndef ZG_LO_THREE_FIRST
 #define ZG_LO_THREE_FIRST 1  // tiles with nine positions in ten open: three-byte pass before the four-byte pass; 0: never
 #endif
@@ -1356,7 +1359,7 @@ __global__ __launch_bounds__(G::lo_threads) void k_match_lo(const uint8_t *__res
     const uint64_t tail_room = ce - t0;
     const uint32_t tail_room32 = tail_room < 0x7FFFFFFFull ? (uint32_t)tail_room : 0x7FFFFFFFu;
     // almost every position of the tile open: the three-byte pass first (see lo_pass)
-    const bool three_first = ZG_LO_THREE_FIRST != 0 && mp.min_len == 3u && (uint64_t)n_open * 10u >= (t1 - t0) * 9u;
+    const bool three_first = ZG_LO_THREE_FIRST != 0 && mp.min_len == 3u && (uint64_t)n_open * 10u >= (t1 - t0) * (uint64_t)ZG_LO_THREE_FIRST_TENTHS;
     stage_tile(data, three_first ? next3 : next4, base, w0, nbytes, nlinks, s_data, s_next, tid, G::lo_threads, G::data_lds);
     __syncthreads();
 #ifdef ZG_DEBUG_PHASES
