@@ -63,6 +63,9 @@ pub mod compress {
 
     /// New item: compress from any `Read` into any `Write` without holding the whole input in memory; the bytes
     /// written are those `compress` returns for the whole input.  Returns (input bytes, stream bytes).
+    /// The library's default context is locked for the whole call and `reader` / `writer` run on threads of the
+    /// library: a reader or writer that itself calls into this crate (`compress`, `adler32`, ...) would wait for
+    /// that lock for ever.
     pub fn compress_stream<R: std::io::Read + Send, W: std::io::Write + Send>(
         reader: &mut R, writer: &mut W, strategy: &Strategy,
     ) -> std::io::Result<(u64, u64)> {

@@ -65,16 +65,53 @@ fn test_units_and_trees_equal_the_crates_own() {
     let units: Vec<LZ77Unit> = gpu.compress(&data);
     assert_eq!(units, own.compress(&data));
     assert_eq!(LZ77Compressor::with_window_size((1 << 15) + 1).window_size, 1 << 15);
-    // code lengths: equal to the crate's whenever its heap meets no tie between internal nodes; always of the
-    // same total cost
+    // Code tables.  The crate's heap leaves the order of two internal nodes of equal weight open (FreqNode::cmp,
+    // src/huffman.rs:103-116, over a HashMap's iteration order), so its code LENGTHS may differ between two runs in
+    // such a tie; whatever the order, both trees are optimal prefix codes over the same symbols.  Checked here:
+    // the same symbols, the same total cost (sum of count x length), a full Kraft sum on both sides -- and the same
+    // maps outright when the lengths agree, i.e. whenever no such tie was met (canonical codes follow from the
+    // lengths alone).
     let (mut lt, mut dt) = HuffmanTree::from_lz77(&units, &gpu);
     lt.assign();
     dt.assign();
     let (mut lo, mut d_o) = zlib::huffman::HuffmanTree::from_lz77(&units, &own);
     lo.assign();
     d_o.assign();
-    assert_eq!(lt.encodings().unwrap().len(), lo.encodings().unwrap().len());
-    assert_eq!(dt.encodings().unwrap().len(), d_o.encodings().unwrap().len());
+    let (lo, d_o) = (lo.to_canonical(), d_o.to_canonical());
+    let (lt, dt) = (lt.to_canonical(), dt.to_canonical());
+    let (mut lit_freq, mut dist_freq) = (std::collections::HashMap::new(), std::collections::HashMap::new());
+    for u in &units {
+        match u {
+            LZ77Unit::Literal(b) => *lit_freq.entry(char::from(*b)).or_insert(0usize) += 1,
+            LZ77Unit::Marker(len, dist) => {
+                let lc = char::from_u32(zlib::huffman::get_length_code(*len) as u32).unwrap();
+                let dc = char::from_u32(zlib::huffman::get_distance_code(*dist) as u32).unwrap();
+                *lit_freq.entry(lc).or_insert(0usize) += 1;
+                *dist_freq.entry(dc).or_insert(0usize) += 1;
+            }
+        }
+    }
+    lit_freq.entry(char::from_u32(256).unwrap()).or_insert(1); // the end-of-block symbol, src/huffman.rs:264
+    type Enc = std::collections::HashMap<char, (usize, usize)>;
+    let same_code = |mine: &Enc, theirs: &Enc, freq: &std::collections::HashMap<char, usize>| {
+        let mut a: Vec<&char> = mine.keys().collect();
+        let mut b: Vec<&char> = theirs.keys().collect();
+        a.sort();
+        b.sort();
+        assert_eq!(a, b, "the two trees code different symbols");
+        let cost = |e: &Enc| freq.iter().map(|(s, f)| f * e[s].1).sum::<usize>();
+        assert_eq!(cost(mine), cost(theirs), "the two trees differ in total cost");
+        let kraft = |e: &Enc| e.values().map(|&(_, l)| 1u64 << (32 - l)).sum::<u64>();
+        if mine.len() > 1 {
+            assert_eq!(kraft(mine), 1u64 << 32);
+            assert_eq!(kraft(theirs), 1u64 << 32);
+        }
+        if mine.iter().all(|(s, &(_, l))| theirs[s].1 == l) {
+            assert_eq!(mine, theirs, "equal lengths must give equal canonical codes");
+        }
+    };
+    same_code(lt.encodings().unwrap(), lo.encodings().unwrap(), &lit_freq);
+    same_code(dt.encodings().unwrap(), d_o.encodings().unwrap(), &dist_freq);
 }
 
 #[test]

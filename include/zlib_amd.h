@@ -110,11 +110,14 @@ int zg_compress_multi(const int *devices, int n_devices, const uint8_t *in, size
  *     number; 0 = end of input; (size_t)-1 = failure (ZG_ERR_IO).
  *   write_fn(user, buf, n): take n bytes; non-zero = failure (ZG_ERR_IO).
  * Both are called from threads of the library, never at the same time as
- * themselves.  size_hint: the input's length if known (only sizes the
+ * themselves.  The context (the default one for ctx == NULL) is locked for
+ * the whole call: a callback that calls any zg_* function on the same
+ * context waits for ever -- give such a callback a context of its own.  size_hint: the input's length if known (only sizes the
  * buffers; 0 = unknown).  *in_total / *out_total (may be NULL) receive the byte
  * counts.  With chunk_bytes not a multiple of 16 KiB a segment is
  * chunk_bytes * 16 KiB / gcd of the two; above 1 GiB: ZG_ERR_UNSUPPORTED.
- * zg_compress_file does the same between two paths. */
+ * zg_compress_file does the same between two paths; the two must not name the
+ * same file (ZG_ERR_ARG), and a call that fails removes what it has written. */
 typedef size_t (*zg_read_fn)(void *user, uint8_t *buf, size_t cap);
 typedef int (*zg_write_fn)(void *user, const uint8_t *buf, size_t n);
 int zg_compress_stream(zg_ctx *ctx, zg_read_fn read_fn, void *read_user, zg_write_fn write_fn,
@@ -202,16 +205,19 @@ int zg_adler32_device(zg_ctx *ctx, const void *d_in, size_t n, uint32_t *out);
 
 /* Adler-32 of device memory without any allocation.  No counterpart in the
  * reference: it is for callers that cannot allocate device memory while they
- * run (code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc).  The per-segment sums live in a fixed array inside the
- * library's code object (128 KiB, held by every GPU the library runs on until
- * the process ends) instead of a buffer of the context, so n is limited to
+ * run (tight serving loops, harnesses that forbid hipMalloc).  The
+ * per-segment sums live in a fixed array inside the library's code object
+ * (128 KiB, held by every GPU the library runs on until the process ends)
+ * instead of a buffer of the context, so n is limited to
  * ZG_ADLER32_NOALLOC_MAX bytes (ZG_ERR_CAPACITY beyond).  ctx must be a context
  * from zg_init (NULL: ZG_ERR_ARG -- the default context would have to be
  * created); d_out is a DEVICE pointer to one uint32_t on the ctx's device and
- * holds the checksum when the call returns (the ctx stream is synchronised).
- * All calls on one GPU share that GPU's array: calls that overlap on one GPU
- * (two contexts of the same device used from two threads) race. */
+ * holds the checksum when the call returns.  The kernels run on the ctx's own
+ * stream, which the call synchronises before it returns: it is NOT ordered
+ * after work the caller has queued on other streams and cannot be recorded
+ * into a HIP graph.  All calls on one GPU share that GPU's array; the library
+ * serialises them with a lock per device, so calls on two contexts of one
+ * device from two threads take turns (processes have a copy each). */
 #define ZG_ADLER32_NOALLOC_MAX ((uint64_t)4 << 30)
 int zg_adler32_device_noalloc(zg_ctx *ctx, const void *d_in, size_t n, uint32_t *d_out);
 

@@ -107,9 +107,10 @@ def test_block_builder_out_of_reference_domain(hc):
     while len(fib) < 32:
         fib.append(fib[-1] + fib[-2])
     toks = []
-    for s, c in enumerate(fib[:26]):
-        toks += [s] * min(c, 30000)
+    for s, c in enumerate(fib[1:27]):  # with the end-of-block symbol's 1 an exact Fibonacci series: depth 26
+        toks += [s] * c
     _check(hc, toks, z.DYNAMIC, True)
+    assert max(z.chunk_tables(toks)[0]) == 15
     # deep distance tree as well
     toks = [1, 2, 3]
     dists = [5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145]

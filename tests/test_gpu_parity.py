@@ -156,13 +156,16 @@ def test_conservative_index_kernel(za, z, monkeypatch):
 
 
 @pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0] * 5])
-def test_several_devices_in_one_process_give_the_single_device_stream(za, devices):
+def test_several_devices_in_one_process_give_the_single_device_stream(za, z, devices):
     """zg_compress_multi with the one GPU of the box standing in for several (a context per run): the assembled
-    stream is the single-context stream, whatever the bit phase at which the runs meet."""
+    stream is the oracle's stream for the whole input (and the single-context stream), whatever the bit phase at
+    which the runs meet."""
     for data, chunk in ((za.corpus("mixed", (5 << 20) + 12345, seed=21), 1 << 16), (za.corpus("text", 700_001, seed=22), 1 << 17),
                         (za.corpus("text", 100_000, seed=23), 1 << 20), (b"", 1 << 20), (za.corpus("binary", 3 << 16, seed=24), 1 << 16)):
         for strategy in (za.Strategy.Dynamic, za.Strategy.Fixed):
             got = za.compress_multi(data, devices, strategy, chunk_bytes=chunk)
+            zs = z.DYNAMIC if strategy == za.Strategy.Dynamic else z.FIXED
+            _same(got, z.compress_chunked(data, zs, chunk, fast=True), f"oracle: {len(data)} bytes over {len(devices)} runs")
             _same(got, za.compress(data, strategy, chunk_bytes=chunk), f"{len(data)} bytes over {len(devices)} runs")
             assert sysz.decompress(got) == data
     assert za.compress_multi(b"abc" * 5000, devices, za.Strategy.Raw) == za.compress(b"abc" * 5000, za.Strategy.Raw)
@@ -385,7 +388,7 @@ def test_raw_large(za, z):
 
 
 @pytest.mark.parametrize("world,total,chunk", [(2, 300_000, 65536), (3, 200_000, 16384), (4, 4 << 20, 1 << 20)])
-def test_shard_api_assembles_the_single_gpu_stream(za, world, total, chunk):
+def test_shard_api_assembles_the_single_gpu_stream(za, z, world, total, chunk):
     """zg_shard_begin / zg_shard_finish for every rank's run of chunks (run one after the other on this GPU),
     assembled with the host logic the multi-GPU bench uses, give the stream of a single compress call."""
     import torch
@@ -412,6 +415,7 @@ def test_shard_api_assembles_the_single_gpu_stream(za, world, total, chunk):
         for i, v in enumerate(piece[:1]):
             final[off + i] |= v
         final[off + 1:off + nb] = piece[1:]
+    _same(bytes(final), z.compress_chunked(data, z.DYNAMIC, chunk, fast=True), "oracle")
     _same(bytes(final), za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk), "")
     assert sysz.decompress(bytes(final)) == data
 

@@ -152,7 +152,8 @@ def compress_stream(reader, writer, strategy: Strategy = Strategy.Dynamic, *, ch
     """zlib::compress for input that is not in memory as a whole: `reader.readinto(buffer)` (or `.read(n)`)
     delivers the input, `writer.write(bytes)` receives the stream, a segment of `batch_bytes` at a time while the
     neighbouring segments are read, uploaded and downloaded.  Returns (input bytes, stream bytes); the bytes
-    written are those compress() returns for the whole input."""
+    written are those compress() returns for the whole input.  `ctx` is locked for the whole call: a reader or
+    writer that calls this module on the same context would wait for ever (give it a Context of its own)."""
     ctx = ctx or default_context()
     failure: List[BaseException] = []
 

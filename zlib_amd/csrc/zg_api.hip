@@ -70,6 +70,10 @@ constexpr uint64_t kNoAllocMax = ZG_ADLER32_NOALLOC_MAX;
 constexpr uint64_t kNoAllocSegs = kNoAllocMax / kNoAllocSeg;
 constexpr uint64_t kNoAllocWords64 = kNoAllocSegs + 3 * (kNoAllocSegs / 1024 + 1);  // 64-bit words in all
 static __device__ __align__(256) uint64_t g_noalloc_scratch[kNoAllocWords64];
+// one lock per GPU (a fixed array: taking it allocates nothing): calls on two contexts of one device take turns at
+// that device's copy of the array
+constexpr int kNoAllocLocks = 64;
+static std::mutex g_noalloc_mu[kNoAllocLocks];
 
 }  // namespace
 
@@ -80,7 +84,7 @@ struct zg_ctx {
     hipStream_t copy = nullptr;  // uploads of host input, overlapped with the kernels on `stream`
     std::mutex mu;
     std::string err;
-    DevBuf walk_exit, walk_chunk, shard_buf, far, next, far4, next4, far3, next3, open_list, open_far, open_cnt, rec_len, rec_off, inf_off, inf_len, inf_status, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
+    DevBuf block_off_all, walk_exit, walk_chunk, shard_buf, far, next, far4, next4, far3, next3, open_list, open_far, open_cnt, rec_len, rec_off, inf_off, inf_len, inf_status, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
         scalars, stage_in, stage_out, misc, flag, sub_exit, sub_exit2, merged, tile_cnt, adler_blk;
     // shard state kept between zg_shard_begin and zg_shard_finish
     bool shard_active = false;
@@ -359,11 +363,20 @@ int run_back(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, uint32_t m
     return ZG_OK;
 }
 
-// keeps the bit offsets of blocks [c0, c1) of the current call on the host (the vector has its final size already:
-// the copy is asynchronous and completes with the call's last synchronisation)
+// keeps the bit offsets of blocks [c0, c1) of the current call: batch by batch into a device array of one entry
+// per block (a copy between device buffers, which does not hold the host up), fetched in one piece at the end of the
+// call by fetch_block_offsets -- a copy to pageable host memory after every batch made the host wait for that
+// batch's kernels before it could queue the next batch's upload
 int keep_block_offsets(zg_ctx *c, uint32_t c0, uint32_t c1) {
     if (c->block_offs.size() < c1) return ZG_OK;
-    HIPCHK(hipMemcpyAsync(c->block_offs.data() + c0, c->bit_off.p, (size_t)(c1 - c0) * sizeof(uint64_t),
+    HIPCHK(hipMemcpyAsync(c->block_off_all.as<uint64_t>() + c0, c->bit_off.p, (size_t)(c1 - c0) * sizeof(uint64_t),
+                          hipMemcpyDeviceToDevice, c->stream));
+    return ZG_OK;
+}
+// queued before the call's last synchronisation
+int fetch_block_offsets(zg_ctx *c) {
+    if (c->block_offs.empty()) return ZG_OK;
+    HIPCHK(hipMemcpyAsync(c->block_offs.data(), c->block_off_all.p, c->block_offs.size() * sizeof(uint64_t),
                           hipMemcpyDeviceToHost, c->stream));
     return ZG_OK;
 }
@@ -476,6 +489,7 @@ int compress_device_once(zg_ctx *c, const uint8_t *d_in, size_t n, int strategy,
         } catch (...) {
             return ZG_ERR_NOMEM;
         }
+        HIPCHK(c->block_off_all.ensure((size_t)g.n_chunks * sizeof(uint64_t)));
         // the word the first block begins in; k_zero_seams clears the other words that are ORed into
         LAUNCH(K_MISC, hipMemsetAsync(d_out, 0, std::min<size_t>(bound, 8), c->stream));
         const MatchParams mp{kMaxWindow, 3, 258};  // get_zlib_compressor, src/compress.rs:451-456
@@ -497,6 +511,8 @@ int compress_device_once(zg_ctx *c, const uint8_t *d_in, size_t n, int strategy,
         rc = run_adler(c, d_in, n);
         if (rc) return rc;
         LAUNCH(K_MISC, launch_trailer(d_out, &sc->carry, sc->adler, 0, 0, 1, 1, &sc->out_bytes, c->stream));
+        rc = fetch_block_offsets(c);
+        if (rc) return rc;
     }
     Scalars h;
     HIPCHK(hipMemcpyAsync(&h, c->scalars.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -572,7 +588,7 @@ void zg_destroy(zg_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf *bufs[] = {&c->walk_exit, &c->walk_chunk, &c->shard_buf, &c->far, &c->next, &c->far4, &c->next4, &c->far3, &c->next3, &c->open_list, &c->open_far, &c->open_cnt, &c->rec_len, &c->rec_off, &c->inf_off, &c->inf_len, &c->inf_status, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
+    DevBuf *bufs[] = {&c->block_off_all, &c->walk_exit, &c->walk_chunk, &c->shard_buf, &c->far, &c->next, &c->far4, &c->next4, &c->far3, &c->next3, &c->open_list, &c->open_far, &c->open_cnt, &c->rec_len, &c->rec_off, &c->inf_off, &c->inf_len, &c->inf_status, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
                       &c->block_bits, &c->bit_off, &c->tile_bits, &c->adler_part, &c->scalars, &c->stage_in,
                       &c->stage_out, &c->misc, &c->flag, &c->sub_exit, &c->sub_exit2, &c->merged, &c->tile_cnt,
                       &c->adler_blk};
@@ -704,6 +720,7 @@ int compress_batch_once(zg_ctx *c, const uint8_t *d_in, size_t stride, const uin
     if (n_records > 0xFFFFFFFFull) return ZG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     if (out_cap < zg_compress_batch_bound(stride, n_records, strategy)) return ZG_ERR_CAPACITY;
+    c->block_offs.clear();  // zg_last_block_offsets speaks of whole-stream calls only
     int rc = init_scalars(c, 0);  // carry = byte offset of the next stream
     if (rc) return rc;
     Scalars *sc = c->scalars.as<Scalars>();
@@ -1020,6 +1037,7 @@ int zg_adler32_device_noalloc(zg_ctx *c, const void *d_in, size_t n, uint32_t *d
     if (!c || !d_out || (!d_in && n)) return ZG_ERR_ARG;
     if (n > kNoAllocMax) return ZG_ERR_CAPACITY;  // more segments than the fixed scratch holds
     std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::mutex> dev_lk(g_noalloc_mu[(unsigned)c->device % kNoAllocLocks]);  // held until the stream is idle
     HIPCHK(hipSetDevice(c->device));
     const uint32_t nseg = (uint32_t)((n + kNoAllocSeg - 1) / kNoAllocSeg);
     uint32_t *partial = reinterpret_cast<uint32_t *>(c->noalloc_scratch);
@@ -1171,6 +1189,7 @@ int shard_begin_locked(zg_ctx *c, const void *d_in, size_t halo, size_t n, int s
         } catch (...) {
             return ZG_ERR_NOMEM;
         }
+        HIPCHK(c->block_off_all.ensure((size_t)g.n_chunks * sizeof(uint64_t)));
         LAUNCH(K_MISC, hipMemsetAsync(c->shard_buf.p, 0, 8, c->stream));  // see compress_device_once
         for (uint32_t c0 = 0; c0 < g.n_chunks; c0 += (uint32_t)bc) {
             const uint32_t c1 = (uint32_t)std::min<uint64_t>(g.n_chunks, (uint64_t)c0 + bc);
@@ -1183,6 +1202,8 @@ int shard_begin_locked(zg_ctx *c, const void *d_in, size_t halo, size_t n, int s
             if (rc) return rc;
         }
         rc = run_adler(c, g.data + halo, n);
+        if (rc) return rc;
+        rc = fetch_block_offsets(c);
         if (rc) return rc;
         Scalars h;
         HIPCHK(hipMemcpyAsync(&h, c->scalars.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -1488,7 +1509,11 @@ int compress_stream_locked(zg_ctx *c, zg_read_fn read_fn, void *read_user, zg_wr
     if (unit > ((size_t)1 << 30)) return ZG_ERR_UNSUPPORTED;
     size_t seg = std::max<size_t>(1, plan.batch_chunks * plan.chunk_bytes / unit) * unit;
     if (size_hint && size_hint < seg) seg = (size_t)((size_hint + unit) / unit) * unit;  // room for the hint + 1 byte
-    const size_t halo_max = std::min<size_t>(kMaxWindow, seg);
+    // never shorter than the window: the halo of a segment is taken from the one segment before it, and every chunk
+    // must see the 32 KiB of input before it, as in a call on the whole input
+    const size_t seg_min = (kMaxWindow + unit - 1) / unit * unit;
+    if (seg < seg_min) seg = seg_min;
+    const size_t halo_max = kMaxWindow;
     HIPCHK(hipSetDevice(c->device));
 
     StreamIn in[2];
@@ -1740,8 +1765,15 @@ int zg_compress_file(zg_ctx *ctx, const char *in_path, const char *out_path, int
         return ZG_ERR_IO;
     }
     uint64_t hint = 0;
-    struct stat st;
-    if (fstat(fileno(fi), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) hint = (uint64_t)st.st_size;
+    struct stat st, st_out;
+    const bool have_st = fstat(fileno(fi), &st) == 0;
+    if (have_st && S_ISREG(st.st_mode) && st.st_size > 0) hint = (uint64_t)st.st_size;
+    // the output is created (and truncated) before the first read: it must not be the input
+    if (have_st && stat(out_path, &st_out) == 0 && st.st_dev == st_out.st_dev && st.st_ino == st_out.st_ino) {
+        fclose(fi);
+        c->err = std::string("input and output are the same file: ") + in_path;
+        return ZG_ERR_ARG;
+    }
     FILE *fo = fopen(out_path, "wb");
     if (!fo) {
         fclose(fi);
@@ -1754,8 +1786,43 @@ int zg_compress_file(zg_ctx *ctx, const char *in_path, const char *out_path, int
         c->err = std::string("cannot finish ") + out_path;
         rc = ZG_ERR_IO;
     }
+    if (rc) (void)remove(out_path);  // no partial stream is left behind
     return rc;
 }
+
+#ifdef ZG_INDEX_DEBUG
+// Measurement hook (debug builds only): the three indexes of n bytes of device memory, `reps` times, nothing else.
+// Returns the mean milliseconds of a launch, or a negative status.
+double zg_debug_index_only(zg_ctx *c, const void *d_in, size_t n, int reps) {
+    if (!c || !d_in || n < 65536) return -1.0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (hipSetDevice(c->device) != hipSuccess) return -2.0;
+    if (init_scalars(c, 0)) return -3.0;
+    const uint64_t span = n;
+    DevBuf *bufs[6] = {&c->far, &c->next, &c->far4, &c->next4, &c->far3, &c->next3};
+    for (DevBuf *b : bufs)
+        if (b->ensure(span * 2 + 64) != hipSuccess) return -4.0;
+    IndexSet set;
+    set.add(5, c->far.as<uint16_t>(), c->next.as<uint16_t>());
+    set.add(4, c->far4.as<uint16_t>(), c->next4.as<uint16_t>());
+    set.add(3, c->far3.as<uint16_t>(), c->next3.as<uint16_t>());
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -5.0;
+    uint32_t *status = &c->scalars.as<Scalars>()->status;
+    const uint8_t *data = static_cast<const uint8_t *>(d_in);
+    (void)launch_index(data, n, 0, n, 0, kMaxWindow, set, 0, status, false, 0, 0, c->stream);  // warm-up
+    (void)hipEventRecord(a, c->stream);
+    for (int i = 0; i < reps; i++)
+        if (launch_index(data, n, 0, n, 0, kMaxWindow, set, 0, status, false, 0, 0, c->stream) != hipSuccess) return -6.0;
+    (void)hipEventRecord(b, c->stream);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -7.0;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return (double)ms / (reps > 0 ? reps : 1);
+}
+#endif
 
 size_t zg_last_block_offsets(zg_ctx *ctx, uint64_t *bit_offsets, size_t cap) {
     int rc = 0;

@@ -26,6 +26,7 @@
 #include "zg_internal.h"
 #include "zg_match_util.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 #ifndef ZG_MATCH_STEPS
@@ -89,7 +90,7 @@ __device__ __forceinline__ uint32_t key_hash<4>(uint32_t lo, uint32_t) {
 }
 template <>
 __device__ __forceinline__ uint32_t key_hash<5>(uint32_t lo, uint32_t hi) {
-    return lo * 0x9E3779B1u + (hi & 0xFFu) * 0x85EBCA6Bu;
+    return lo * 0x9E3779B1u + __umul24(hi & 0xFFu, 0x85EBCBu);  // (a 24-bit product issues at the full rate)
 }
 
 // the first K bytes at view position p (p + K <= n_view): low four in lo, the fifth in hi
@@ -205,19 +206,19 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t *__restrict__ data, 
     }
 }
 
-// k_index_r: the fast variant.  One wave per segment walks its positions DOWNWARD in batches of 64, with a
-// single LDS table and no walking:
+// k_index_r: the fast variant.  One wave per segment walks its positions DOWNWARD, with a single LDS table and no
+// walking along chains:
 //   head[h]  the lowest member inserted so far, i.e. the nearest member above the position being inserted.
-//            One ds_wrxchg on it hands every lane its successor, lanes of the same batch included (lane l
-//            takes position u + 63 - l), PROVIDED the LDS serialises same-address lanes of one instruction in
-//            ascending lane order.  gfx950 does (probed over 6.5*10^8 colliding exchanges,
-//            tools/probe/probe_exch.hip); the kernel still checks every returned value (a successor handed
-//            out of order is not above the lane's own position) and raises bit 1 of *status, upon which the
-//            host redoes the call with k_index.
+//            One returning LDS atomic on it hands every lane its successor, lanes of the same instruction
+//            included, PROVIDED the LDS serves same-address lanes of one instruction in ascending lane order.
+//            gfx950 does (probed over 10^9 colliding operations: tools/probe/probe_exch.hip for the exchange,
+//            tools/probe/probe_max.hip for the maximum with reads among the writes); the kernel still checks every
+//            returned value (a successor handed out of order is not above the lane's own position) and raises
+//            bit 1 of *status, upon which the host redoes the call with k_index.
 // The successor gives next[] of the lane's own position: a contiguous store.  far[p] is read off the same
-// table when the walk has come down to p - window: head[h(p)] is then the lowest member at or above the
-// batch holding p - window, and at most a few links inside that batch (kept in LDS) lead from it to the lowest
-// member at or above p - window itself.  Positions less than a window above the first position of their slot
+// table when the walk has come down to p - window: the look-up sits right behind the insert of position
+// p - window in the same instruction, so the head it sees is the lowest member at or above p - window.
+// Positions less than a window above the first position of their slot
 // (the start of the data; the first byte of an isolated record) are answered in one sweep when the walk
 // reaches that first position.  Slots start on the grid of batch groups, so a group never straddles two.
 // A segment walks `window` positions above and below the seg_len ones it owns; the host picks seg_len so that
@@ -241,8 +242,29 @@ constexpr uint32_t kIdxSegMin = 16u << 10, kIdxSegCap = ZG_IDX_CAP_KB << 10;  //
 constexpr uint32_t kIdxRBits = ZG_IDX_BITS;
 constexpr uint32_t kIdxRBuckets = 1u << kIdxRBits;
 
+// -DZG_INDEX_DEBUG: begin and end (100 MHz ticks) of every wave of the last k_index_r launches, for
+// tools/debug_index.py (how the segments of a launch fill the machine)
+#ifdef ZG_INDEX_DEBUG
+__device__ unsigned long long g_idbg[1 + 3 * 65536];
+__device__ unsigned long long g_iph[8];  // cycles per phase of a group, summed over all waves; [7]: groups
+extern "C" int zg_index_debug(unsigned long long *out, size_t n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_idbg), n * sizeof(unsigned long long));
+}
+extern "C" int zg_index_debug_reset() {
+    const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_iph), zero, sizeof zero);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_idbg), zero, sizeof zero[0]);
+}
+extern "C" int zg_index_debug_phases(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_iph), 8 * sizeof(unsigned long long));
+}
+#define IDBG(...) __VA_ARGS__
+#else
+#define IDBG(...)
+#endif
+
 template <int K>
-__device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_link, uint32_t seg, uint32_t seg_len,
+__device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t seg, uint32_t seg_len,
                                                 const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
                                                 uint64_t r1, uint64_t far_lo, uint32_t window,
                                                 uint16_t *__restrict__ far, uint16_t *__restrict__ next,
@@ -272,6 +294,7 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_li
     uint16_t *far_seg = far + (a0 - base);
     uint16_t *next_seg = next + (a0 - base);
     bool violated = false;
+    IDBG(unsigned long long iph[8] = {0, 0, 0, 0, 0, 0, 0, 0};)
 
     // (offsets are taken from a base at or below every clamped offset, so that they are unsigned 32-bit values:
     // a scalar base plus a vector offset, without the 64-bit address arithmetic of a signed index)
@@ -280,7 +303,7 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_li
     };
     const int32_t low = last < 0 ? last : 0;
     const uint8_t *dlow = dseg + low;
-    auto raw_at = [&](uint32_t q) -> RawKey<K> {  // branch-free: the offset is clamped into the view
+    auto raw_at = [&](uint32_t q) __attribute__((always_inline)) -> RawKey<K> {  // branch-free: the offset is clamped into the view
         const int32_t qc = (int32_t)q < last ? (int32_t)q : last;
         const uint32_t off = (uint32_t)(qc - low);
         RawKey<K> r;
@@ -289,7 +312,7 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_li
         if (K > 4) __builtin_memcpy(&r.b, dlow + off + 4u, 4);
         return r;
     };
-    auto hash_of = [&](RawKey<K> r, uint32_t q, bool exact) -> uint32_t {
+    auto hash_of = [&](RawKey<K> r, uint32_t q, bool exact) __attribute__((always_inline)) -> uint32_t {
         if (exact) return key_hash<K>(r.a, r.b) >> (32 - kIdxRBits);  // the load was not clamped
         const uint32_t sh = (int32_t)q > last ? ((uint32_t)((int32_t)q - last) & 7u) * 8u : 0u;
         if (K > 4) {
@@ -299,15 +322,37 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_li
         return key_hash<K>(r.a >> (sh & 31u), 0u) >> (32 - kIdxRBits);
     };
 
-    // One group = kIdxGroup batches, highest first.  Batch k of the group at qg inserts positions
-    // [u, u + 64), u = qg + 64 * (kIdxGroup - 1 - k), and right behind its exchange reads the table for the 64
-    // positions u + window + lane; none of these LDS operations waits for another, so the wave waits for the
-    // LDS once per group.  Keys of the next group are loaded meanwhile.
+    // The table holds kEnc - position of the lowest member so far (0 = empty; positions are relative to a0 and
+    // small): the walk runs downward, so a newer member has the larger entry, and an LDS atomic MAX with return is
+    // at once
+    //   an insert   (operand = the position's entry, larger than what is there: the entry is replaced and the old
+    //                one, the member's successor, comes back), and
+    //   a look-up   (operand 0: nothing changes, the entry comes back).
+    // One group = kIdxSpan positions, highest first, handled in one of two ways:
+    //   insert mode (no far[] is answered by this group): 16 instructions, lane l of instruction k inserts position
+    //       qg + kIdxSpan - 1 - (64 k + l);
+    //   interleaved mode: 32 instructions; in instruction i the even lane 2j inserts position p = qg + kIdxSpan - 1 -
+    //       (32 i + j) and the odd lane 2j + 1 looks up the bucket of position p + window.  The LDS serves the lanes
+    //       of one instruction in ascending lane order (probed: tools/probe/probe_max.hip, reads among inserts
+    //       included), so that look-up sees exactly the members at or above p -- the lowest of them is the farthest
+    //       member p + window can reach, far[p + window], with no walk along the links of the batch (a look-up behind
+    //       a whole batch of 64 inserts had to follow up to 63 of them: a fifth of the kernel's time on random
+    //       bytes, three fifths on packed records).
+    // None of these LDS operations waits for another, so the wave waits for the LDS once per group.  Keys of the
+    // next group are loaded meanwhile.  The kernel is bound by the number of instructions one wave can issue, so the
+    // common case (fast_ins, fast_il: every key inside the view, every look-up wanted, no slots) is spelled out
+    // without branches: about fifteen instructions per LDS operation.
+    constexpr uint32_t kEnc = 0x7FFFFFFFu;
     struct GroupKeys {
-        RawKey<K> m[kIdxGroup], r[kIdxGroup];  // keys of the positions inserted / looked up
+        RawKey<K> k[2 * kIdxGroup];  // insert mode uses the first half
     };
+    const uint32_t pair = lane >> 1;
+    const bool odd = (lane & 1u) != 0;
+    const uint32_t odd01 = odd ? 1u : 0u;
+    const uint32_t look_off = odd ? window : 0u;  // the key of an odd lane lies a window above the lane's position
+    int32_t worst = 1;  // least (entry of the lane's position - entry handed back): 0 or below = handed out of order
     auto ins_pos = [&](uint32_t qg, int k) { return qg + (kIdxSpan - 1u) - ((uint32_t)k * 64 + lane); };
-    auto look_pos = [&](uint32_t qg, int k) { return qg + (kIdxGroup - 1u - (uint32_t)k) * 64 + window + lane; };
+    auto il_pos = [&](uint32_t qg, int i) { return qg + (kIdxSpan - 1u) - ((uint32_t)i * 32 + pair); };
     // does any / every position looked up by the group at qg get its far[] from it?  (uniform)
     auto look_none = [&](uint32_t qg, uint32_t slot_end) {
         return qg + window >= q_b || qg + window >= slot_end || qg + window + kIdxSpan <= q_far;
@@ -317,106 +362,196 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_li
     };
     auto slot_end_of = [&](uint32_t qg, uint32_t relg) { return iso_bytes ? qg + (iso_bytes - relg) : 0xFFFFFFFFu; };
     // qg may be "below zero" (wrapped): its loads are clamped into the view and never used
-    auto load_keys = [&](GroupKeys &buf, uint32_t qg, bool with_look) {
-#pragma unroll
-        for (int k = 0; k < (int)kIdxGroup; k++) {
-            const uint32_t qi = ins_pos(qg, k);
-            buf.m[k] = raw_at((int32_t)qi > 0 ? qi : 0u);
-        }
+    auto load_keys = [&](GroupKeys &buf, uint32_t qg, bool with_look) __attribute__((always_inline)) {
         if (with_look) {
 #pragma unroll
+            for (int i = 0; i < 2 * (int)kIdxGroup; i++) {
+                const uint32_t q = il_pos(qg, i) + look_off;
+                buf.k[i] = raw_at((int32_t)q > 0 ? q : 0u);
+            }
+        } else {
+#pragma unroll
             for (int k = 0; k < (int)kIdxGroup; k++) {
-                const uint32_t ql = look_pos(qg, k);
-                buf.r[k] = raw_at((int32_t)ql > 0 ? ql : 0u);
+                const uint32_t qi = ins_pos(qg, k);
+                buf.k[k] = raw_at((int32_t)qi > 0 ? qi : 0u);
+                // (every entry is written on both paths: the compiler would otherwise merge the two paths' last
+                // stores into one through a pointer chosen at run time, and the keys would live in scratch memory)
+                buf.k[kIdxGroup + k] = buf.k[k];
             }
         }
     };
+    // the same for a group whose every key load lies inside the view: one pointer per lane, the instruction's place
+    // in the group a constant offset
+    auto load_raw = [](const uint8_t *ptr) __attribute__((always_inline)) {
+        RawKey<K> r;
+        __builtin_memcpy(&r.a, ptr, 4);
+        r.b = 0;
+        if (K > 4) __builtin_memcpy(&r.b, ptr + 4, 4);
+        return r;
+    };
+    auto load_keys_fast = [&](GroupKeys &buf, uint32_t qg, bool with_look) __attribute__((always_inline)) {
+        if (with_look) {
+            const uint8_t *const p0 = dseg + (il_pos(qg, 0) + look_off);
+#pragma unroll
+            for (int i = 0; i < 2 * (int)kIdxGroup; i++) buf.k[i] = load_raw(p0 - 32 * i);
+        } else {
+            const uint8_t *const p0 = dseg + ins_pos(qg, 0);
+#pragma unroll
+            for (int k = 0; k < (int)kIdxGroup; k++) buf.k[kIdxGroup + k] = buf.k[k] = load_raw(p0 - 64 * k);
+        }
+    };
+    auto table_max = [&](uint32_t h, uint32_t operand) __attribute__((always_inline)) {
+        return __hip_atomic_fetch_max(&s_head[h], operand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto hash_exact = [](RawKey<K> r) __attribute__((always_inline)) { return key_hash<K>(r.a, r.b) >> (32 - kIdxRBits); };
+    // far[] of the positions less than a window above the first position of a slot (or of the data), answered when
+    // the walk has reached that first position qg: every member of the slot is in the table and nothing below it
+    auto sweep_slot = [&](uint32_t qg, uint32_t slot_end) __attribute__((always_inline)) {
+        uint32_t pe = qg + reach < q_b ? qg + reach : q_b;
+        pe = pe < slot_end ? pe : slot_end;
+        const uint32_t lo = qg > q_far ? qg : q_far;
+        for (uint32_t pb = qg + ((lo - qg) & ~63u); pb < pe; pb += kIdxSpan) {
+            RawKey<K> r[kIdxGroup];
+#pragma unroll
+            for (int j = 0; j < (int)kIdxGroup; j++) r[j] = raw_at(pb + (uint32_t)j * 64 + lane);
+#pragma unroll
+            for (int j = 0; j < (int)kIdxGroup; j++) {
+                const uint32_t p = pb + (uint32_t)j * 64 + lane;
+                const uint32_t m1 = s_head[hash_of(r[j], p, false)];
+                if (p >= q_far && p < pe) st16(far_seg, p, (p + K <= n_rel && m1) ? p - (kEnc - m1) : 0u);
+            }
+        }
+    };
+
+    // ---- the common case ----
+    // fast_ins: 16 x 64 inserts; kNext: the positions are owned (their next[] is stored)
+    auto fast_ins = [&](GroupKeys &buf, uint32_t qg, uint32_t qn, bool look_n, bool fast_n, auto next_c) __attribute__((always_inline)) {
+        constexpr bool kNext = decltype(next_c)::value;
+        IDBG(const long long dt0 = clock64();)
+        GroupKeys cur;
+#pragma unroll
+        for (int i = 0; i < 2 * (int)kIdxGroup; i++) cur.k[i] = buf.k[i];
+        if (fast_n) load_keys_fast(buf, qn, look_n);
+        else load_keys(buf, qn, look_n);
+        const uint32_t e0 = kEnc - ins_pos(qg, 0);  // entry of instruction k's position: e0 + 64 k
+        uint32_t got[kIdxGroup];
+#pragma unroll
+        for (int k = 0; k < (int)kIdxGroup; k++) got[k] = table_max(hash_exact(cur.k[k]), e0 + 64u * (uint32_t)k);
+        IDBG(const long long dt1 = clock64(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long dt2 = clock64();)
+        uint16_t *const np = next_seg + ins_pos(qg, 0);
+#pragma unroll
+        for (int k = 0; k < (int)kIdxGroup; k++) {
+            const uint32_t d = e0 + 64u * (uint32_t)k - got[k];  // distance to the successor; huge if there is none
+            worst = (int32_t)d < worst ? (int32_t)d : worst;
+            if (kNext) np[-64 * k] = (uint16_t)(d <= window ? d : 0u);
+        }
+        IDBG(const long long dt3 = clock64(); iph[0] += dt1 - dt0; iph[1] += dt2 - dt1; iph[2] += dt3 - dt2; iph[7] += 1;)
+    };
+    // fast_il: 32 x (32 inserts, 32 look-ups)
+    auto fast_il = [&](GroupKeys &buf, uint32_t qg, uint32_t qn, bool look_n, bool fast_n, auto next_c) __attribute__((always_inline)) {
+        constexpr bool kNext = decltype(next_c)::value;
+        IDBG(const long long dt0 = clock64();)
+        GroupKeys cur;
+#pragma unroll
+        for (int i = 0; i < 2 * (int)kIdxGroup; i++) cur.k[i] = buf.k[i];
+        if (fast_n) load_keys_fast(buf, qn, look_n);
+        else load_keys(buf, qn, look_n);
+        // Entry of instruction i's position: e0 + 32 i.  Odd lanes take one more, so that for both kinds of lane
+        // d = (that) - (entry handed back) is 1 or more when all is in order: an insert gets a member above its
+        // position, a look-up one at or above it.  Even lanes: d = distance to the successor; odd: window + 1 - far.
+        const uint32_t e0 = kEnc - il_pos(qg, 0) + odd01;
+        const uint32_t ins_mask = odd ? 0u : 0xFFFFFFFFu;
+        uint32_t got[2 * kIdxGroup];
+#pragma unroll
+        for (int i = 0; i < 2 * (int)kIdxGroup; i++)
+            got[i] = table_max(hash_exact(cur.k[i]), (e0 + 32u * (uint32_t)i) & ins_mask);
+        IDBG(const long long dt1 = clock64(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long dt2 = clock64();)
+        const int32_t sgn = odd ? -1 : 1, off = odd ? (int32_t)window + 1 : 0;
+        const uint32_t lim = window + odd01;
+#pragma unroll
+        for (int i = 0; i < 2 * (int)kIdxGroup; i++) {
+            const uint32_t d = e0 + 32u * (uint32_t)i - got[i];
+            worst = (int32_t)d < worst ? (int32_t)d : worst;
+            const uint32_t val = (uint32_t)(__mul24(sgn, (int32_t)d) + off);  // d, or window + 1 - d
+            got[i] = d <= lim ? val : 0u;  // no successor within the window (an empty bucket gives a huge d)
+        }
+        // even lanes store next[p], odd lanes far[p + window]: one store per instruction through a pointer of the
+        // lane's own, the instruction's place in the group being a constant offset
+        if (kNext || odd) {
+            uint16_t *const sp = odd ? far_seg + (il_pos(qg, 0) + window) : next_seg + il_pos(qg, 0);
+#pragma unroll
+            for (int i = 0; i < 2 * (int)kIdxGroup; i++) sp[-32 * i] = (uint16_t)got[i];
+        }
+        IDBG(const long long dt3 = clock64(); iph[3] += dt1 - dt0; iph[4] += dt2 - dt1; iph[5] += dt3 - dt2; iph[6] += 1;)
+    };
+
+    // ---- everything else: groups at the ends of the view, of the owned range or of a slot ----
     // buf holds the keys of the group at qg and is refilled for the group kIdxDepth below (at qn, which looks
     // positions up if look_n).  kNext / kLook: 0 = the group stores no next[] / answers no far[], 1 = every lane
     // does, 2 = decided lane by lane.  kFull: every key of the group lies well inside the view.
-    auto group = [&](GroupKeys &buf, uint32_t qg, uint32_t slot_end, bool sweep, uint32_t qn, bool look_n, auto full_c,
-                     auto next_c, auto look_c) {
+    auto group_ins = [&](GroupKeys &buf, uint32_t qg, uint32_t slot_end, bool sweep, uint32_t qn, bool look_n,
+                         auto full_c, auto next_c) __attribute__((always_inline)) {
         constexpr bool full = decltype(full_c)::value;
-        constexpr int kNext = decltype(next_c)::value, kLook = decltype(look_c)::value;
-        const GroupKeys cur = buf;
+        constexpr int kNext = decltype(next_c)::value;
+        GroupKeys cur;
+#pragma unroll
+        for (int i = 0; i < 2 * (int)kIdxGroup; i++) cur.k[i] = buf.k[i];
         load_keys(buf, qn, look_n);
-        uint32_t old1[kIdxGroup], e1[kIdxGroup];
-        bool lv[kIdxGroup];
+        uint32_t got[kIdxGroup];
 #pragma unroll
         for (int k = 0; k < (int)kIdxGroup; k++) {
-            const uint32_t qi = ins_pos(qg, k), ql = look_pos(qg, k);
+            const uint32_t qi = ins_pos(qg, k);
             const bool valid = full || (qi < q_top && qi + K <= n_rel);
-            const uint32_t h = hash_of(cur.m[k], qi, full);
-            old1[k] = 0;
-            if (valid) old1[k] = atomicExch(&s_head[h], qi + 1u);  // member inserted just before me (+1)
-            if (kLook) {
-                lv[k] = kLook == 1 || (ql >= q_far && ql < q_b && ql < slot_end && (full || ql + K <= n_rel));
-                e1[k] = s_head[hash_of(cur.r[k], ql, full)];
-            }
+            got[k] = table_max(hash_of(cur.k[k], qi, full), valid ? kEnc - qi : 0u);  // the member inserted just before
         }
-        uint32_t e[kIdxGroup];
-        bool hop = false;
 #pragma unroll
         for (int k = 0; k < (int)kIdxGroup; k++) {
-            const uint32_t qi = ins_pos(qg, k), ql = look_pos(qg, k);
-            violated |= old1[k] != 0u && old1[k] <= qi + 1u;
-            const uint32_t d = old1[k] ? old1[k] - 1u - qi : 0u;
+            const uint32_t qi = ins_pos(qg, k);
+            const bool valid = full || (qi < q_top && qi + K <= n_rel);
+            const uint32_t d = kEnc - qi - got[k];  // distance to the successor; huge if there is none
+            const int32_t chk = valid ? (int32_t)d : 1;
+            worst = chk < worst ? chk : worst;
             if (kNext) {
                 // a link counts within the window and within the slot
-                const uint32_t nd = (d <= window && old1[k] - 1u < slot_end) ? d : 0u;
+                const uint32_t nd = (valid && d <= window && kEnc - got[k] < slot_end) ? d : 0u;
                 if (kNext == 1 || (qi >= q_a && qi < q_b)) st16(next_seg, qi, nd);
             }
-            if (kLook) {
-                s_link[qi - qg] = d;
-                e[k] = e1[k] ? e1[k] - 1u : ql;  // a valid position is a member itself: the bucket is not empty
-                hop |= lv[k] && e[k] < ql - window;
-            }
         }
-        if (kLook) {
-            if (__any(hop)) {
-                // members of the batch below p - window: follow the batch's links upward.  All the reads of a
-                // round are issued before any is used (the index is wrapped into the group for lanes that have
-                // arrived), so a round costs one LDS latency.
-                for (uint32_t guard = 0; guard < 64; ++guard) {
-                    uint32_t l[kIdxGroup];
+        if (sweep) sweep_slot(qg, slot_end);
+    };
+    auto group_il = [&](GroupKeys &buf, uint32_t qg, uint32_t slot_end, bool sweep, uint32_t qn, bool look_n,
+                        auto full_c, auto next_c, auto look_c) __attribute__((always_inline)) {
+        constexpr bool full = decltype(full_c)::value;
+        constexpr int kNext = decltype(next_c)::value, kLook = decltype(look_c)::value;
+        GroupKeys cur;
 #pragma unroll
-                    for (int k = 0; k < (int)kIdxGroup; k++) l[k] = s_link[(e[k] - qg) & (kIdxSpan - 1u)];
-                    bool more = false;
+        for (int i = 0; i < 2 * (int)kIdxGroup; i++) cur.k[i] = buf.k[i];
+        load_keys(buf, qn, look_n);
+        uint32_t got[2 * kIdxGroup];
+        uint32_t vmask = 0;  // bit i: this lane's operation in instruction i is a valid insert / a wanted look-up
 #pragma unroll
-                    for (int k = 0; k < (int)kIdxGroup; k++) {
-                        const uint32_t ql = look_pos(qg, k);
-                        const bool go = lv[k] && e[k] < ql - window;
-                        const uint32_t en = l[k] ? e[k] + l[k] : ql;
-                        e[k] = go ? en : e[k];
-                        more |= go && en < ql - window;
-                    }
-                    if (!__any(more)) break;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < (int)kIdxGroup; k++) {
-                const uint32_t ql = look_pos(qg, k);
-                if (kLook == 1 || (ql >= q_far && ql < q_b && ql < slot_end))
-                    st16(far_seg, ql, lv[k] ? ql - e[k] : 0u);
-            }
+        for (int i = 0; i < 2 * (int)kIdxGroup; i++) {
+            const uint32_t pos = il_pos(qg, i), kp = pos + look_off;
+            const bool v_ins = full || (pos < q_top && pos + K <= n_rel);
+            const bool v_look = kLook == 1 || (kp >= q_far && kp < q_b && kp < slot_end && (full || kp + K <= n_rel));
+            const bool v = odd ? v_look : v_ins;
+            vmask |= (v ? 1u : 0u) << i;
+            got[i] = table_max(hash_of(cur.k[i], kp, full), (v && !odd) ? kEnc - pos : 0u);
         }
-        if (sweep) {
-            // qg is the first position of a slot: every member of the slot is in the table and nothing below it
-            uint32_t pe = qg + reach < q_b ? qg + reach : q_b;
-            pe = pe < slot_end ? pe : slot_end;
-            const uint32_t lo = qg > q_far ? qg : q_far;
-            for (uint32_t pb = qg + ((lo - qg) & ~63u); pb < pe; pb += kIdxSpan) {
-                RawKey<K> r[kIdxGroup];
+        uint16_t *const sp = odd ? far_seg + (il_pos(qg, 0) + window) : next_seg + il_pos(qg, 0);
 #pragma unroll
-                for (int j = 0; j < (int)kIdxGroup; j++) r[j] = raw_at(pb + (uint32_t)j * 64 + lane);
-#pragma unroll
-                for (int j = 0; j < (int)kIdxGroup; j++) {
-                    const uint32_t p = pb + (uint32_t)j * 64 + lane;
-                    const uint32_t m1 = s_head[hash_of(r[j], p, false)];
-                    if (p >= q_far && p < pe) st16(far_seg, p, (p + K <= n_rel && m1) ? p + 1u - m1 : 0u);
-                }
-            }
+        for (int i = 0; i < 2 * (int)kIdxGroup; i++) {
+            const uint32_t pos = il_pos(qg, i);
+            const bool v = (vmask >> i) & 1u;
+            const uint32_t d = kEnc - pos + odd01 - got[i];  // as in fast_il
+            const int32_t chk = v ? (int32_t)d : 1;
+            worst = chk < worst ? chk : worst;
+            const uint32_t nd = (v && d <= window && kEnc - got[i] < slot_end) ? d : 0u;
+            const uint32_t fd = (v && d <= window + 1u) ? window + 1u - d : 0u;
+            const bool st = odd ? v : (kNext == 1 || (kNext == 2 && pos >= q_a && pos < q_b));
+            if (st) sp[-32 * i] = (uint16_t)(odd ? fd : nd);
         }
+        if (sweep) sweep_slot(qg, slot_end);
     };
     const uint32_t n_groups = (q_top + kIdxSpan - 1u) / kIdxSpan;
     // offset of a group's first position inside its slot (isolated slots only): relg for the group being
@@ -424,48 +559,55 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t *s_li
     auto rel_down = [&](uint32_t rel) { return rel >= kIdxSpan ? rel - kIdxSpan : rel + iso_bytes - kIdxSpan; };
     uint32_t relg = iso_bytes ? (uint32_t)((a0 - iso_first + (uint64_t)(n_groups - 1u) * kIdxSpan) % iso_bytes) : 0u;
     uint32_t reln = relg;
-    GroupKeys ring[kIdxDepth];
-#pragma unroll
-    for (uint32_t j = 0; j < kIdxDepth; j++) {
-        const uint32_t qn = (n_groups - 1u - j) * kIdxSpan;
-        load_keys(ring[j], qn, !look_none(qn, slot_end_of(qn, reln)));
+    static_assert(kIdxDepth == 1, "one group of keys in flight");
+    GroupKeys ring0;
+    {
+        const uint32_t qn = (n_groups - 1u) * kIdxSpan;
+        load_keys(ring0, qn, !look_none(qn, slot_end_of(qn, reln)));
         if (iso_bytes) reln = rel_down(reln);
     }
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
     using C2 = std::integral_constant<int, 2>;
+    // every key of the group at q (and of the positions it looks up) lies well inside the view
+    auto is_full = [&](uint32_t q) { return q + kIdxSpan <= q_top && q + kIdxSpan + window + 72u <= n_rel; };
     for (uint32_t g = n_groups; g > 0;) {
-#pragma unroll
-        for (uint32_t j = 0; j < kIdxDepth; j++) {  // unrolled, so that the ring stays in registers
-            if (g == 0) break;
+        {
             --g;
             const uint32_t qg = g * kIdxSpan, qn = qg - kIdxDepth * kIdxSpan;
             const uint32_t slot_end = slot_end_of(qg, relg);
             const bool sweep = iso_bytes ? relg == 0u : (g == 0u && a0 == r0);
             const bool look_n = g >= kIdxDepth && !look_none(qn, slot_end_of(qn, reln));
-            const bool full = qg + kIdxSpan <= q_top && qg + kIdxSpan + window + 72u <= n_rel;
+            const bool full = is_full(qg), fast_n = g >= kIdxDepth && is_full(qn);
             const bool n0 = qg >= q_b || qg + kIdxSpan <= q_a, n1 = qg >= q_a && qg + kIdxSpan <= q_b;
             const bool l0 = look_none(qg, slot_end), l1 = look_all(qg, slot_end);
-            GroupKeys &buf = ring[j];
-            if (full && n1 && l1)
-                group(buf, qg, slot_end, sweep, qn, look_n, std::true_type{}, C1{}, C1{});
+            const bool fast = full && iso_bytes == 0u && !sweep;
+            GroupKeys &buf = ring0;
+            if (fast && n1 && l1)
+                fast_il(buf, qg, qn, look_n, fast_n, std::true_type{});
+            else if (fast && n0 && l1)
+                fast_il(buf, qg, qn, look_n, fast_n, std::false_type{});
+            else if (fast && n1 && l0)
+                fast_ins(buf, qg, qn, look_n, fast_n, std::true_type{});
+            else if (fast && n0 && l0)
+                fast_ins(buf, qg, qn, look_n, fast_n, std::false_type{});
             else if (full && n1 && l0)
-                group(buf, qg, slot_end, sweep, qn, look_n, std::true_type{}, C1{}, C0{});
-            else if (full && n0 && l1)
-                group(buf, qg, slot_end, sweep, qn, look_n, std::true_type{}, C0{}, C1{});
+                group_ins(buf, qg, slot_end, sweep, qn, look_n, std::true_type{}, C1{});
             else if (full && n0 && l0)
-                group(buf, qg, slot_end, sweep, qn, look_n, std::true_type{}, C0{}, C0{});
+                group_ins(buf, qg, slot_end, sweep, qn, look_n, std::true_type{}, C0{});
             else if (l0)
-                group(buf, qg, slot_end, sweep, qn, look_n, std::false_type{}, C2{}, C0{});
+                group_ins(buf, qg, slot_end, sweep, qn, look_n, std::false_type{}, C2{});
             else
-                group(buf, qg, slot_end, sweep, qn, look_n, std::false_type{}, C2{}, C2{});
+                group_il(buf, qg, slot_end, sweep, qn, look_n, std::false_type{}, C2{}, C2{});
             if (iso_bytes) {
                 relg = rel_down(relg);
                 reln = rel_down(reln);
             }
         }
     }
+    violated |= worst <= 0;
     if (__any(violated) && lane == 0) atomicOr(status, 2u);
+    IDBG(if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_iph[i], iph[i]);)
 }
 
 // One workgroup (one wave) per segment and key length: blockIdx.y selects the key length, so that all the
@@ -474,21 +616,48 @@ __global__ __launch_bounds__(64) void k_index_r(const uint8_t *__restrict__ data
                                                  uint64_t r1, uint64_t far_lo, uint32_t window, IndexSet set,
                                                  uint64_t base, uint32_t *status, uint64_t iso_first,
                                                  uint32_t iso_bytes, uint32_t seg_len) {
-    __shared__ uint32_t s_head[kIdxRBuckets];  // position + 1, 0 = empty
-    __shared__ uint32_t s_link[kIdxSpan];      // distance to the successor, positions of the current group
+    __shared__ uint32_t s_head[kIdxRBuckets];  // a constant minus the lowest member so far, 0 = empty
+#ifdef ZG_IDX_LDS_PAD  // measurement: fewer waves per CU
+    __shared__ uint32_t s_pad[ZG_IDX_LDS_PAD];
+    if (n_view == 0x123456789ull) s_pad[threadIdx.x] = 1;
+#endif
     const int key = set.key[blockIdx.y];
     uint16_t *far = set.far[blockIdx.y];
     uint16_t *next = set.next[blockIdx.y];
+#ifdef ZG_INDEX_DEBUG
+    const unsigned long long dbg_t0 = wall_clock64();
+    struct DbgEnd {
+        unsigned long long t0;
+        int key;
+        __device__ ~DbgEnd() {
+            if (threadIdx.x == 0) {
+                const unsigned long long slot = atomicAdd(&g_idbg[0], 1ull);
+                if (slot < 65536) {
+                    g_idbg[1 + 3 * slot] = t0;
+                    g_idbg[2 + 3 * slot] = wall_clock64();
+                    g_idbg[3 + 3 * slot] = (unsigned long long)blockIdx.x | ((unsigned long long)key << 32);
+                }
+            }
+        }
+    } dbg_end{dbg_t0, key};
+#endif
     if (key == 5)
-        index_r_segment<5>(s_head, s_link, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base,
+        index_r_segment<5>(s_head, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base,
                            status, iso_first, iso_bytes);
     else if (key == 4)
-        index_r_segment<4>(s_head, s_link, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base,
+        index_r_segment<4>(s_head, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base,
                            status, iso_first, iso_bytes);
     else
-        index_r_segment<3>(s_head, s_link, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base,
+        index_r_segment<3>(s_head, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base,
                            status, iso_first, iso_bytes);
 }
+
+#ifdef ZG_INDEX_DEBUG
+extern "C" int zg_index_waves_per_cu() {
+    int nb = 0;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_index_r, 64, 0) == hipSuccess ? nb : -1;
+}
+#endif
 
 // k_index_brute: the same two arrays for small windows (LZ77Compressor's default is 144), one thread per
 // position, by direct scan of the window on either side.
@@ -572,7 +741,14 @@ hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint6
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         cus = 256;
-    const uint64_t slots = 4ull * (uint64_t)cus, n_pos = r1 - r0;
+    // waves of this kernel that a CU holds at once (its LDS table allows five, its registers two per SIMD)
+    static const int per_cu = [] {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_index_r, 64, 0) != hipSuccess || nb <= 0) nb = 4;
+        if (const char *e = std::getenv("ZLIB_AMD_INDEX_WAVES")) nb = atoi(e) > 0 ? atoi(e) : nb;  // measurement hook
+        return nb;
+    }();
+    const uint64_t slots = (uint64_t)per_cu * (uint64_t)cus, n_pos = r1 - r0;
     const uint64_t reach = iso_bytes && iso_bytes < window ? iso_bytes : window;
     // isolated records are all alike: long segments; otherwise kIdxSegCap, or half of it while that still
     // leaves the machine no more than two fillings (the tail of the last filling then runs on emptier CUs)
