@@ -228,12 +228,8 @@ __global__ __launch_bounds__(64) void k_index(const uint8_t *__restrict__ data, 
 #endif
 constexpr uint32_t kIdxGroup = ZG_IDX_GROUP;         // batches of 64 positions handled together
 constexpr uint32_t kIdxSpan = 64 * kIdxGroup;
-#ifndef ZG_IDX_DEPTH
-#define ZG_IDX_DEPTH 1
-#endif
-constexpr uint32_t kIdxDepth = ZG_IDX_DEPTH;         // groups whose keys are in flight
 #ifndef ZG_IDX_CAP_KB
-#define ZG_IDX_CAP_KB 256
+#define ZG_IDX_CAP_KB 1024
 #endif
 constexpr uint32_t kIdxSegMin = 16u << 10, kIdxSegCap = ZG_IDX_CAP_KB << 10;  // positions owned by one k_index_r wave
 #ifndef ZG_IDX_BITS
@@ -263,13 +259,23 @@ extern "C" int zg_index_debug_phases(unsigned long long *out) {
 #define IDBG(...)
 #endif
 
-template <int K>
-__device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t seg, uint32_t seg_len,
+// LDS of one k_index_r wave (32-bit words): the table; and, for the kernel without slots, the bytes of the current
+// group's two regions (its own positions, and the positions a window above whose far[] it answers; each kIdxSpan
+// bytes, the key bytes behind the last one and alignment slack) and the group's results (next[] and far[], 16 bits
+// each), which leave in 16-byte stores.
+constexpr uint32_t kIdxStageBytes = kIdxSpan + 256;
+constexpr uint32_t kIdxLdsWordsStream = kIdxRBuckets + 2 * kIdxStageBytes / 4 + 2 * kIdxSpan / 2;
+constexpr uint32_t kIdxLdsWordsIso = kIdxRBuckets;
+
+template <int K, bool kIso>
+__device__ __forceinline__ void index_r_segment(uint32_t *s_mem, uint32_t seg, uint32_t seg_len,
                                                 const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
                                                 uint64_t r1, uint64_t far_lo, uint32_t window,
                                                 uint16_t *__restrict__ far, uint16_t *__restrict__ next,
                                                 uint64_t base, uint32_t *status, uint64_t iso_first,
-                                                uint32_t iso_bytes) {
+                                                uint32_t iso_bytes_arg) {
+    const uint32_t iso_bytes = kIso ? iso_bytes_arg : 0u;
+    uint32_t *const s_head = s_mem;
     const uint32_t lane = threadIdx.x;
     const uint64_t a = r0 + (uint64_t)seg * seg_len;
     if (a >= r1) return;
@@ -338,10 +344,7 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t seg, 
     //       member p + window can reach, far[p + window], with no walk along the links of the batch (a look-up behind
     //       a whole batch of 64 inserts had to follow up to 63 of them: a fifth of the kernel's time on random
     //       bytes, three fifths on packed records).
-    // None of these LDS operations waits for another, so the wave waits for the LDS once per group.  Keys of the
-    // next group are loaded meanwhile.  The kernel is bound by the number of instructions one wave can issue, so the
-    // common case (fast_ins, fast_il: every key inside the view, every look-up wanted, no slots) is spelled out
-    // without branches: about fifteen instructions per LDS operation.
+    // None of these LDS operations waits for another, so the wave waits for the LDS once per group.
     constexpr uint32_t kEnc = 0x7FFFFFFFu;
     struct GroupKeys {
         RawKey<K> k[2 * kIdxGroup];  // insert mode uses the first half
@@ -361,7 +364,8 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t seg, 
         return qg + window >= q_far && qg + window + kIdxSpan <= q_b && qg + window + kIdxSpan <= slot_end;
     };
     auto slot_end_of = [&](uint32_t qg, uint32_t relg) { return iso_bytes ? qg + (iso_bytes - relg) : 0xFFFFFFFFu; };
-    // qg may be "below zero" (wrapped): its loads are clamped into the view and never used
+    // keys by one load per lane and instruction; qg may be "below zero" (wrapped): its loads are clamped into the
+    // view and never used
     auto load_keys = [&](GroupKeys &buf, uint32_t qg, bool with_look) __attribute__((always_inline)) {
         if (with_look) {
 #pragma unroll
@@ -380,30 +384,9 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t seg, 
             }
         }
     };
-    // the same for a group whose every key load lies inside the view: one pointer per lane, the instruction's place
-    // in the group a constant offset
-    auto load_raw = [](const uint8_t *ptr) __attribute__((always_inline)) {
-        RawKey<K> r;
-        __builtin_memcpy(&r.a, ptr, 4);
-        r.b = 0;
-        if (K > 4) __builtin_memcpy(&r.b, ptr + 4, 4);
-        return r;
-    };
-    auto load_keys_fast = [&](GroupKeys &buf, uint32_t qg, bool with_look) __attribute__((always_inline)) {
-        if (with_look) {
-            const uint8_t *const p0 = dseg + (il_pos(qg, 0) + look_off);
-#pragma unroll
-            for (int i = 0; i < 2 * (int)kIdxGroup; i++) buf.k[i] = load_raw(p0 - 32 * i);
-        } else {
-            const uint8_t *const p0 = dseg + ins_pos(qg, 0);
-#pragma unroll
-            for (int k = 0; k < (int)kIdxGroup; k++) buf.k[kIdxGroup + k] = buf.k[k] = load_raw(p0 - 64 * k);
-        }
-    };
     auto table_max = [&](uint32_t h, uint32_t operand) __attribute__((always_inline)) {
         return __hip_atomic_fetch_max(&s_head[h], operand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    auto hash_exact = [](RawKey<K> r) __attribute__((always_inline)) { return key_hash<K>(r.a, r.b) >> (32 - kIdxRBits); };
     // far[] of the positions less than a window above the first position of a slot (or of the data), answered when
     // the walk has reached that first position qg: every member of the slot is in the table and nothing below it
     auto sweep_slot = [&](uint32_t qg, uint32_t slot_end) __attribute__((always_inline)) {
@@ -423,80 +406,13 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t seg, 
         }
     };
 
-    // ---- the common case ----
-    // fast_ins: 16 x 64 inserts; kNext: the positions are owned (their next[] is stored)
-    auto fast_ins = [&](GroupKeys &buf, uint32_t qg, uint32_t qn, bool look_n, bool fast_n, auto next_c) __attribute__((always_inline)) {
-        constexpr bool kNext = decltype(next_c)::value;
-        IDBG(const long long dt0 = clock64();)
-        GroupKeys cur;
-#pragma unroll
-        for (int i = 0; i < 2 * (int)kIdxGroup; i++) cur.k[i] = buf.k[i];
-        if (fast_n) load_keys_fast(buf, qn, look_n);
-        else load_keys(buf, qn, look_n);
-        const uint32_t e0 = kEnc - ins_pos(qg, 0);  // entry of instruction k's position: e0 + 64 k
-        uint32_t got[kIdxGroup];
-#pragma unroll
-        for (int k = 0; k < (int)kIdxGroup; k++) got[k] = table_max(hash_exact(cur.k[k]), e0 + 64u * (uint32_t)k);
-        IDBG(const long long dt1 = clock64(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long dt2 = clock64();)
-        uint16_t *const np = next_seg + ins_pos(qg, 0);
-#pragma unroll
-        for (int k = 0; k < (int)kIdxGroup; k++) {
-            const uint32_t d = e0 + 64u * (uint32_t)k - got[k];  // distance to the successor; huge if there is none
-            worst = (int32_t)d < worst ? (int32_t)d : worst;
-            if (kNext) np[-64 * k] = (uint16_t)(d <= window ? d : 0u);
-        }
-        IDBG(const long long dt3 = clock64(); iph[0] += dt1 - dt0; iph[1] += dt2 - dt1; iph[2] += dt3 - dt2; iph[7] += 1;)
-    };
-    // fast_il: 32 x (32 inserts, 32 look-ups)
-    auto fast_il = [&](GroupKeys &buf, uint32_t qg, uint32_t qn, bool look_n, bool fast_n, auto next_c) __attribute__((always_inline)) {
-        constexpr bool kNext = decltype(next_c)::value;
-        IDBG(const long long dt0 = clock64();)
-        GroupKeys cur;
-#pragma unroll
-        for (int i = 0; i < 2 * (int)kIdxGroup; i++) cur.k[i] = buf.k[i];
-        if (fast_n) load_keys_fast(buf, qn, look_n);
-        else load_keys(buf, qn, look_n);
-        // Entry of instruction i's position: e0 + 32 i.  Odd lanes take one more, so that for both kinds of lane
-        // d = (that) - (entry handed back) is 1 or more when all is in order: an insert gets a member above its
-        // position, a look-up one at or above it.  Even lanes: d = distance to the successor; odd: window + 1 - far.
-        const uint32_t e0 = kEnc - il_pos(qg, 0) + odd01;
-        const uint32_t ins_mask = odd ? 0u : 0xFFFFFFFFu;
-        uint32_t got[2 * kIdxGroup];
-#pragma unroll
-        for (int i = 0; i < 2 * (int)kIdxGroup; i++)
-            got[i] = table_max(hash_exact(cur.k[i]), (e0 + 32u * (uint32_t)i) & ins_mask);
-        IDBG(const long long dt1 = clock64(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long dt2 = clock64();)
-        const int32_t sgn = odd ? -1 : 1, off = odd ? (int32_t)window + 1 : 0;
-        const uint32_t lim = window + odd01;
-#pragma unroll
-        for (int i = 0; i < 2 * (int)kIdxGroup; i++) {
-            const uint32_t d = e0 + 32u * (uint32_t)i - got[i];
-            worst = (int32_t)d < worst ? (int32_t)d : worst;
-            const uint32_t val = (uint32_t)(__mul24(sgn, (int32_t)d) + off);  // d, or window + 1 - d
-            got[i] = d <= lim ? val : 0u;  // no successor within the window (an empty bucket gives a huge d)
-        }
-        // even lanes store next[p], odd lanes far[p + window]: one store per instruction through a pointer of the
-        // lane's own, the instruction's place in the group being a constant offset
-        if (kNext || odd) {
-            uint16_t *const sp = odd ? far_seg + (il_pos(qg, 0) + window) : next_seg + il_pos(qg, 0);
-#pragma unroll
-            for (int i = 0; i < 2 * (int)kIdxGroup; i++) sp[-32 * i] = (uint16_t)got[i];
-        }
-        IDBG(const long long dt3 = clock64(); iph[3] += dt1 - dt0; iph[4] += dt2 - dt1; iph[5] += dt3 - dt2; iph[6] += 1;)
-    };
-
-    // ---- everything else: groups at the ends of the view, of the owned range or of a slot ----
-    // buf holds the keys of the group at qg and is refilled for the group kIdxDepth below (at qn, which looks
-    // positions up if look_n).  kNext / kLook: 0 = the group stores no next[] / answers no far[], 1 = every lane
-    // does, 2 = decided lane by lane.  kFull: every key of the group lies well inside the view.
-    auto group_ins = [&](GroupKeys &buf, uint32_t qg, uint32_t slot_end, bool sweep, uint32_t qn, bool look_n,
-                         auto full_c, auto next_c) __attribute__((always_inline)) {
+    // ---- the general forms: any group, lane by lane ----
+    // cur holds the keys of the group at qg.  kNext / kLook: 0 = the group stores no next[] / answers no far[], 1 =
+    // every lane does, 2 = decided lane by lane.  kFull: every key of the group lies well inside the view.
+    auto group_ins = [&](const GroupKeys &cur, uint32_t qg, uint32_t slot_end, bool sweep, auto full_c,
+                         auto next_c) __attribute__((always_inline)) {
         constexpr bool full = decltype(full_c)::value;
         constexpr int kNext = decltype(next_c)::value;
-        GroupKeys cur;
-#pragma unroll
-        for (int i = 0; i < 2 * (int)kIdxGroup; i++) cur.k[i] = buf.k[i];
-        load_keys(buf, qn, look_n);
         uint32_t got[kIdxGroup];
 #pragma unroll
         for (int k = 0; k < (int)kIdxGroup; k++) {
@@ -519,14 +435,10 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t seg, 
         }
         if (sweep) sweep_slot(qg, slot_end);
     };
-    auto group_il = [&](GroupKeys &buf, uint32_t qg, uint32_t slot_end, bool sweep, uint32_t qn, bool look_n,
-                        auto full_c, auto next_c, auto look_c) __attribute__((always_inline)) {
+    auto group_il = [&](const GroupKeys &cur, uint32_t qg, uint32_t slot_end, bool sweep, auto full_c, auto next_c,
+                        auto look_c) __attribute__((always_inline)) {
         constexpr bool full = decltype(full_c)::value;
         constexpr int kNext = decltype(next_c)::value, kLook = decltype(look_c)::value;
-        GroupKeys cur;
-#pragma unroll
-        for (int i = 0; i < 2 * (int)kIdxGroup; i++) cur.k[i] = buf.k[i];
-        load_keys(buf, qn, look_n);
         uint32_t got[2 * kIdxGroup];
         uint32_t vmask = 0;  // bit i: this lane's operation in instruction i is a valid insert / a wanted look-up
 #pragma unroll
@@ -538,12 +450,16 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t seg, 
             vmask |= (v ? 1u : 0u) << i;
             got[i] = table_max(hash_of(cur.k[i], kp, full), (v && !odd) ? kEnc - pos : 0u);
         }
+        // even lanes store next[p], odd lanes far[p + window], through a pointer of the lane's own
         uint16_t *const sp = odd ? far_seg + (il_pos(qg, 0) + window) : next_seg + il_pos(qg, 0);
 #pragma unroll
         for (int i = 0; i < 2 * (int)kIdxGroup; i++) {
             const uint32_t pos = il_pos(qg, i);
             const bool v = (vmask >> i) & 1u;
-            const uint32_t d = kEnc - pos + odd01 - got[i];  // as in fast_il
+            // Odd lanes take one more than the entry of their position, so that for both kinds of lane d is 1 or
+            // more when all is in order: an insert gets a member above its position, a look-up one at or above it.
+            // Even lanes: d = distance to the successor; odd: d = window + 1 - far.
+            const uint32_t d = kEnc - pos + odd01 - got[i];
             const int32_t chk = v ? (int32_t)d : 1;
             worst = chk < worst ? chk : worst;
             const uint32_t nd = (v && d <= window && kEnc - got[i] < slot_end) ? d : 0u;
@@ -553,55 +469,216 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t seg, 
         }
         if (sweep) sweep_slot(qg, slot_end);
     };
-    const uint32_t n_groups = (q_top + kIdxSpan - 1u) / kIdxSpan;
-    // offset of a group's first position inside its slot (isolated slots only): relg for the group being
-    // handled, reln for the one whose keys are being loaded
-    auto rel_down = [&](uint32_t rel) { return rel >= kIdxSpan ? rel - kIdxSpan : rel + iso_bytes - kIdxSpan; };
-    uint32_t relg = iso_bytes ? (uint32_t)((a0 - iso_first + (uint64_t)(n_groups - 1u) * kIdxSpan) % iso_bytes) : 0u;
-    uint32_t reln = relg;
-    static_assert(kIdxDepth == 1, "one group of keys in flight");
-    GroupKeys ring0;
-    {
-        const uint32_t qn = (n_groups - 1u) * kIdxSpan;
-        load_keys(ring0, qn, !look_none(qn, slot_end_of(qn, reln)));
-        if (iso_bytes) reln = rel_down(reln);
-    }
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
     using C2 = std::integral_constant<int, 2>;
+    auto general = [&](const GroupKeys &cur, uint32_t qg, uint32_t slot_end, bool sweep, bool full, bool n0, bool n1,
+                       bool l0, bool l1) __attribute__((always_inline)) {
+        if (kIso && full && n1 && l0)
+            group_ins(cur, qg, slot_end, sweep, std::true_type{}, C1{});
+        else if (kIso && full && n0 && l0)
+            group_ins(cur, qg, slot_end, sweep, std::true_type{}, C0{});
+        else if (l0)
+            group_ins(cur, qg, slot_end, sweep, std::false_type{}, C2{});
+        else
+            group_il(cur, qg, slot_end, sweep, std::false_type{}, C2{}, C2{});
+        (void)l1;
+    };
+    const uint32_t n_groups = (q_top + kIdxSpan - 1u) / kIdxSpan;
     // every key of the group at q (and of the positions it looks up) lies well inside the view
     auto is_full = [&](uint32_t q) { return q + kIdxSpan <= q_top && q + kIdxSpan + window + 72u <= n_rel; };
-    for (uint32_t g = n_groups; g > 0;) {
+
+    if constexpr (kIso) {
+        // Slots (records): the general forms, the keys of the next group loaded while this one is handled.
+        // relg / reln: offset of a group's first position inside its slot, for the group being handled / the one
+        // whose keys are being loaded
+        auto rel_down = [&](uint32_t rel) { return rel >= kIdxSpan ? rel - kIdxSpan : rel + iso_bytes - kIdxSpan; };
+        uint32_t relg = (uint32_t)((a0 - iso_first + (uint64_t)(n_groups - 1u) * kIdxSpan) % iso_bytes);
+        uint32_t reln = relg;
+        GroupKeys buf;
         {
+            const uint32_t qn = (n_groups - 1u) * kIdxSpan;
+            load_keys(buf, qn, !look_none(qn, slot_end_of(qn, reln)));
+            reln = rel_down(reln);
+        }
+        for (uint32_t g = n_groups; g > 0;) {
             --g;
-            const uint32_t qg = g * kIdxSpan, qn = qg - kIdxDepth * kIdxSpan;
+            const uint32_t qg = g * kIdxSpan, qn = qg - kIdxSpan;
             const uint32_t slot_end = slot_end_of(qg, relg);
-            const bool sweep = iso_bytes ? relg == 0u : (g == 0u && a0 == r0);
-            const bool look_n = g >= kIdxDepth && !look_none(qn, slot_end_of(qn, reln));
-            const bool full = is_full(qg), fast_n = g >= kIdxDepth && is_full(qn);
+            const bool sweep = relg == 0u;
+            const bool look_n = g >= 1u && !look_none(qn, slot_end_of(qn, reln));
             const bool n0 = qg >= q_b || qg + kIdxSpan <= q_a, n1 = qg >= q_a && qg + kIdxSpan <= q_b;
-            const bool l0 = look_none(qg, slot_end), l1 = look_all(qg, slot_end);
-            const bool fast = full && iso_bytes == 0u && !sweep;
-            GroupKeys &buf = ring0;
-            if (fast && n1 && l1)
-                fast_il(buf, qg, qn, look_n, fast_n, std::true_type{});
-            else if (fast && n0 && l1)
-                fast_il(buf, qg, qn, look_n, fast_n, std::false_type{});
-            else if (fast && n1 && l0)
-                fast_ins(buf, qg, qn, look_n, fast_n, std::true_type{});
-            else if (fast && n0 && l0)
-                fast_ins(buf, qg, qn, look_n, fast_n, std::false_type{});
-            else if (full && n1 && l0)
-                group_ins(buf, qg, slot_end, sweep, qn, look_n, std::true_type{}, C1{});
-            else if (full && n0 && l0)
-                group_ins(buf, qg, slot_end, sweep, qn, look_n, std::true_type{}, C0{});
-            else if (l0)
-                group_ins(buf, qg, slot_end, sweep, qn, look_n, std::false_type{}, C2{});
-            else
-                group_il(buf, qg, slot_end, sweep, qn, look_n, std::false_type{}, C2{}, C2{});
-            if (iso_bytes) {
-                relg = rel_down(relg);
-                reln = rel_down(reln);
+            GroupKeys cur;
+#pragma unroll
+            for (int i = 0; i < 2 * (int)kIdxGroup; i++) cur.k[i] = buf.k[i];
+            load_keys(buf, qn, look_n);
+            general(cur, qg, slot_end, sweep, is_full(qg), n0, n1, look_none(qg, slot_end), look_all(qg, slot_end));
+            relg = rel_down(relg);
+            reln = rel_down(reln);
+        }
+    } else {
+        // No slots: the common case -- every key inside the view, every look-up wanted, the whole group owned or not
+        // owned -- is spelled out without branches (the kernel is bound by the number of instructions it issues and
+        // by the address unit's work: about fifteen instructions per LDS operation), and its bytes and results pass
+        // through LDS: a group's two regions of bytes come in by two 16-byte loads and one 4-byte load per lane (a
+        // key load per lane and instruction, unaligned and with neighbouring lanes in two different regions, kept
+        // the address unit busy longer than everything else took), the results leave in 16-byte stores.
+        uint8_t *const s_stage = reinterpret_cast<uint8_t *>(s_mem + kIdxRBuckets);
+        uint16_t *const s_out = reinterpret_cast<uint16_t *>(s_stage + 2 * kIdxStageBytes);
+        const uint32_t mis_a = (uint32_t)(reinterpret_cast<uintptr_t>(dseg) & 15u);           // groups start on multiples of
+        const uint32_t mis_b = (uint32_t)(reinterpret_cast<uintptr_t>(dseg + window) & 15u);  // kIdxSpan from a0
+        // results leave in aligned 16-byte stores
+        const bool out_aligned = (reinterpret_cast<uintptr_t>(next_seg) & 15u) == 0 &&
+                                 (reinterpret_cast<uintptr_t>(far_seg + window) & 15u) == 0;
+        // the staged loads start up to 15 bytes below the group's first byte and end up to 272 behind its last
+        auto is_fast = [&](uint32_t q) {
+            return out_aligned && q + kIdxSpan <= q_top && q + kIdxSpan + window + 320u <= n_rel && (q != 0u || a0 >= 16u) &&
+                   (q >= q_b || q + kIdxSpan <= q_a || (q >= q_a && q + kIdxSpan <= q_b)) &&
+                   (look_none(q, 0xFFFFFFFFu) || look_all(q, 0xFFFFFFFFu)) && !(q == 0u && a0 == r0);
+        };
+        struct RawBlocks {
+            uint4 a, b;
+            uint32_t at, bt;
+        };
+        auto prefetch = [&](RawBlocks &r, uint32_t q, bool with_look) __attribute__((always_inline)) {
+            const uint8_t *const pa = dseg + q - mis_a;
+            r.a = *reinterpret_cast<const uint4 *>(pa + lane * 16u);
+            r.at = *reinterpret_cast<const uint32_t *>(pa + kIdxSpan + lane * 4u);
+            if (with_look) {
+                const uint8_t *const pb = dseg + q + window - mis_b;
+                r.b = *reinterpret_cast<const uint4 *>(pb + lane * 16u);
+                r.bt = *reinterpret_cast<const uint32_t *>(pb + kIdxSpan + lane * 4u);
+            } else {
+                r.b = r.a;  // (both paths write every field: see load_keys)
+                r.bt = r.at;
+            }
+        };
+        auto stage = [&](const RawBlocks &r, bool with_look) __attribute__((always_inline)) {
+            *reinterpret_cast<uint4 *>(s_stage + lane * 16u) = r.a;
+            *reinterpret_cast<uint32_t *>(s_stage + kIdxSpan + lane * 4u) = r.at;
+            if (with_look) {
+                *reinterpret_cast<uint4 *>(s_stage + kIdxStageBytes + lane * 16u) = r.b;
+                *reinterpret_cast<uint32_t *>(s_stage + kIdxStageBytes + kIdxSpan + lane * 4u) = r.bt;
+            }
+            asm volatile("" ::: "memory");  // the typed reads below are of these bytes
+        };
+        // bucket of the key that starts sh bytes into the two staged words d0, d1
+        auto staged_hash = [&](uint32_t d0, uint32_t d1, uint32_t sh) __attribute__((always_inline)) {
+            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+            return key_hash<K>(lo, K > 4 ? d1 >> (sh * 8u) : 0u) >> (32 - kIdxRBits);
+        };
+        // fast_ins: 16 x 64 inserts; kNext: the positions are owned (their next[] is stored)
+        auto fast_ins = [&](uint32_t qg, auto next_c) __attribute__((always_inline)) {
+            constexpr bool kNext = decltype(next_c)::value;
+            IDBG(const long long dt0 = clock64();)
+            const uint32_t kb0 = mis_a + (kIdxSpan - 1u) - lane;  // byte of instruction 0's key; instruction k: 64 k below
+            const uint32_t *const wp = reinterpret_cast<const uint32_t *>(s_stage + (kb0 & ~3u) - 64u * (kIdxGroup - 1u));
+            const uint32_t sh = kb0 & 3u;
+            const uint32_t e0 = kEnc - ins_pos(qg, 0);  // entry of instruction k's position: e0 + 64 k
+            // (all the reads of the staged bytes first: the compiler keeps a read behind every earlier atomic, which
+            // it takes to touch the same memory, and a read issued behind an atomic waits for that atomic's return)
+            uint32_t kw[kIdxGroup][2], got[kIdxGroup];
+#pragma unroll
+            for (int k = 0; k < (int)kIdxGroup; k++) {
+                kw[k][0] = wp[((int)kIdxGroup - 1 - k) * 16];
+                kw[k][1] = wp[((int)kIdxGroup - 1 - k) * 16 + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < (int)kIdxGroup; k++)
+                got[k] = table_max(staged_hash(kw[k][0], kw[k][1], sh), e0 + 64u * (uint32_t)k);
+            IDBG(const long long dt1 = clock64(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long dt2 = clock64();)
+            uint16_t *const np = next_seg + ins_pos(qg, 0);
+#pragma unroll
+            for (int k = 0; k < (int)kIdxGroup; k++) {
+                const uint32_t d = e0 + 64u * (uint32_t)k - got[k];  // distance to the successor; huge if there is none
+                worst = (int32_t)d < worst ? (int32_t)d : worst;
+                if (kNext) np[-64 * k] = (uint16_t)(d <= window ? d : 0u);
+            }
+            IDBG(const long long dt3 = clock64(); iph[0] += dt1 - dt0; iph[1] += dt2 - dt1; iph[2] += dt3 - dt2; iph[7] += 1;)
+        };
+        // fast_il: 32 x (32 inserts, 32 look-ups)
+        auto fast_il = [&](uint32_t qg, auto next_c) __attribute__((always_inline)) {
+            constexpr bool kNext = decltype(next_c)::value;
+            IDBG(const long long dt0 = clock64();)
+            const uint32_t kb0 = (odd ? kIdxStageBytes + mis_b : mis_a) + (kIdxSpan - 1u) - pair;  // instruction i: 32 i below
+            const uint32_t *const wp = reinterpret_cast<const uint32_t *>(s_stage + (kb0 & ~3u) - 32u * (2u * kIdxGroup - 1u));
+            const uint32_t sh = kb0 & 3u;
+            // Entry of instruction i's position: e0 + 32 i.  Odd lanes take one more, so that for both kinds of lane
+            // d = (that) - (entry handed back) is 1 or more when all is in order: an insert gets a member above its
+            // position, a look-up one at or above it.  Even lanes: d = distance to the successor; odd: window + 1 - far.
+            const uint32_t e0 = kEnc - il_pos(qg, 0) + odd01;
+            const uint32_t ins_mask = odd ? 0u : 0xFFFFFFFFu;
+            uint32_t kw[2 * kIdxGroup][2], got[2 * kIdxGroup];  // (all reads first: see fast_ins)
+#pragma unroll
+            for (int i = 0; i < 2 * (int)kIdxGroup; i++) {
+                kw[i][0] = wp[(2 * (int)kIdxGroup - 1 - i) * 8];
+                kw[i][1] = wp[(2 * (int)kIdxGroup - 1 - i) * 8 + 1];
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * (int)kIdxGroup; i++)
+                got[i] = table_max(staged_hash(kw[i][0], kw[i][1], sh), (e0 + 32u * (uint32_t)i) & ins_mask);
+            IDBG(const long long dt1 = clock64(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long dt2 = clock64();)
+            const int32_t sgn = odd ? -1 : 1, off = odd ? (int32_t)window + 1 : 0;
+            const uint32_t lim = window + odd01;
+            // even lanes: next[p] of the group's positions, odd lanes: far[p + window]; collected in LDS in position
+            // order (instruction i: 32 i entries below instruction 0's)
+            uint16_t *const op = s_out + (odd ? kIdxSpan : 0u) + (kIdxSpan - 1u) - pair - 32u * (2u * kIdxGroup - 1u);
+#pragma unroll
+            for (int i = 0; i < 2 * (int)kIdxGroup; i++) {
+                const uint32_t d = e0 + 32u * (uint32_t)i - got[i];
+                worst = (int32_t)d < worst ? (int32_t)d : worst;
+                const uint32_t val = (uint32_t)(__mul24(sgn, (int32_t)d) + off);  // d, or window + 1 - d
+                got[i] = d <= lim ? val : 0u;  // no successor within the window (an empty bucket gives a huge d)
+            }
+            if (kNext || odd) {
+#pragma unroll
+                for (int i = 0; i < 2 * (int)kIdxGroup; i++) op[(2 * (int)kIdxGroup - 1 - i) * 32] = (uint16_t)got[i];
+            }
+            asm volatile("" ::: "memory");  // the typed reads below are of these entries
+            // 2 x kIdxSpan bytes each: two 16-byte blocks per lane
+            const uint4 *const o4 = reinterpret_cast<const uint4 *>(s_out);
+            uint4 *const f4 = reinterpret_cast<uint4 *>(far_seg + qg + window);
+            f4[lane] = o4[kIdxSpan / 8 + lane];
+            f4[64 + lane] = o4[kIdxSpan / 8 + 64 + lane];
+            if (kNext) {
+                uint4 *const n4 = reinterpret_cast<uint4 *>(next_seg + qg);
+                n4[lane] = o4[lane];
+                n4[64 + lane] = o4[64 + lane];
+            }
+            asm volatile("" ::: "memory");
+            IDBG(const long long dt3 = clock64(); iph[3] += dt1 - dt0; iph[4] += dt2 - dt1; iph[5] += dt3 - dt2; iph[6] += 1;)
+        };
+        static_assert(kIdxSpan == 1024, "two 16-byte blocks per lane and array of results");
+        RawBlocks raw;
+        {
+            const uint32_t q = (n_groups - 1u) * kIdxSpan;
+            if (is_fast(q)) prefetch(raw, q, !look_none(q, 0xFFFFFFFFu));
+            else raw = RawBlocks{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), 0u, 0u};
+        }
+        for (uint32_t g = n_groups; g > 0;) {
+            --g;
+            const uint32_t qg = g * kIdxSpan, qn = qg - kIdxSpan;
+            const bool sweep = g == 0u && a0 == r0;
+            const bool n0 = qg >= q_b || qg + kIdxSpan <= q_a, n1 = qg >= q_a && qg + kIdxSpan <= q_b;
+            const bool l0 = look_none(qg, 0xFFFFFFFFu), l1 = look_all(qg, 0xFFFFFFFFu);
+            const bool fast_n = g >= 1u && is_fast(qn);
+            const bool look_n = fast_n && !look_none(qn, 0xFFFFFFFFu);
+            if (is_fast(qg)) {
+                stage(raw, !l0);
+                if (fast_n) prefetch(raw, qn, look_n);
+                if (l1 && n1)
+                    fast_il(qg, std::true_type{});
+                else if (l1)
+                    fast_il(qg, std::false_type{});
+                else if (n1)
+                    fast_ins(qg, std::true_type{});
+                else
+                    fast_ins(qg, std::false_type{});
+            } else {
+                if (fast_n) prefetch(raw, qn, look_n);
+                GroupKeys cur;
+                load_keys(cur, qg, !l0);
+                general(cur, qg, 0xFFFFFFFFu, sweep, is_full(qg), n0, n1, l0, l1);
             }
         }
     }
@@ -612,11 +689,13 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_head, uint32_t seg, 
 
 // One workgroup (one wave) per segment and key length: blockIdx.y selects the key length, so that all the
 // indexes of a call are built by one launch and share the machine.
+template <bool kIso>
 __global__ __launch_bounds__(64) void k_index_r(const uint8_t *__restrict__ data, uint64_t n_view, uint64_t r0,
                                                  uint64_t r1, uint64_t far_lo, uint32_t window, IndexSet set,
                                                  uint64_t base, uint32_t *status, uint64_t iso_first,
                                                  uint32_t iso_bytes, uint32_t seg_len) {
-    __shared__ uint32_t s_head[kIdxRBuckets];  // a constant minus the lowest member so far, 0 = empty
+    // the table (a constant minus the lowest member so far, 0 = empty) and, without slots, the group's bytes and results
+    __shared__ __attribute__((aligned(16))) uint32_t s_mem[kIso ? kIdxLdsWordsIso : kIdxLdsWordsStream];
 #ifdef ZG_IDX_LDS_PAD  // measurement: fewer waves per CU
     __shared__ uint32_t s_pad[ZG_IDX_LDS_PAD];
     if (n_view == 0x123456789ull) s_pad[threadIdx.x] = 1;
@@ -642,20 +721,20 @@ __global__ __launch_bounds__(64) void k_index_r(const uint8_t *__restrict__ data
     } dbg_end{dbg_t0, key};
 #endif
     if (key == 5)
-        index_r_segment<5>(s_head, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base,
-                           status, iso_first, iso_bytes);
+        index_r_segment<5, kIso>(s_mem, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base, status,
+                                 iso_first, iso_bytes);
     else if (key == 4)
-        index_r_segment<4>(s_head, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base,
-                           status, iso_first, iso_bytes);
+        index_r_segment<4, kIso>(s_mem, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base, status,
+                                 iso_first, iso_bytes);
     else
-        index_r_segment<3>(s_head, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base,
-                           status, iso_first, iso_bytes);
+        index_r_segment<3, kIso>(s_mem, blockIdx.x, seg_len, data, n_view, r0, r1, far_lo, window, far, next, base, status,
+                                 iso_first, iso_bytes);
 }
 
 #ifdef ZG_INDEX_DEBUG
 extern "C" int zg_index_waves_per_cu() {
     int nb = 0;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_index_r, 64, 0) == hipSuccess ? nb : -1;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_index_r<false>, 64, 0) == hipSuccess ? nb : -1;
 }
 #endif
 
@@ -731,29 +810,39 @@ hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint6
         return hipSuccess;
     }
     const uint32_t ny = set.n;
-    // Segment length.  A wave walks its segment plus `reach` positions on either side, and the LDS table lets
-    // four waves share a CU (which keeps its LDS pipeline about 70 % busy: more waves would not help).  The
-    // launch is cut into whole fillings of the machine -- a few waves over would cost a filling of their own:
-    // 256 MiB of 4 KiB records took 5.2 ms with 1026 waves on 1024 places, 3.1 ms with 1023 -- of segments of
-    // about kIdxSegCap, short enough for waves on cheap and on costly data (long runs of one byte make every
-    // lane of a batch collide) to even out over several fillings; longer segments were slower on the mixed corpus.
+    // Segment length.  A wave walks its segment plus `reach` positions on either side.  The launch is cut into whole
+    // fillings of the machine -- a few waves over would cost a filling of their own: 256 MiB of 4 KiB records took
+    // 5.2 ms with 1026 waves on 1024 places, 3.1 ms with 1023.
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         cus = 256;
     // waves of this kernel that a CU holds at once (its LDS table allows five, its registers two per SIMD)
-    static const int per_cu = [] {
+    // waves of the kernel that a CU holds at once.  The occupancy query counts five tables of 32 KiB in the CU's 160 KiB
+    // of LDS; the hardware was seen to admit four, and a plan made for five then needs a second, nearly empty
+    // filling (256 MiB of 4 KiB records: 4.9 ms planned for five, 3.2 ms planned for four).
+    static const int per_cu_stream = [] {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_index_r, 64, 0) != hipSuccess || nb <= 0) nb = 4;
-        if (const char *e = std::getenv("ZLIB_AMD_INDEX_WAVES")) nb = atoi(e) > 0 ? atoi(e) : nb;  // measurement hook
-        return nb;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_index_r<false>, 64, 0) != hipSuccess || nb <= 0) nb = 4;
+        return nb < 4 ? nb : 4;
     }();
+    static const int per_cu_iso = [] {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_index_r<true>, 64, 0) != hipSuccess || nb <= 0) nb = 4;
+        return nb < 4 ? nb : 4;
+    }();
+    static const int cap_env = [] {  // measurement hook: longest segment in KiB
+        const char *e = std::getenv("ZLIB_AMD_INDEX_CAP_KB");
+        return e ? atoi(e) : 0;
+    }();
+    const int per_cu = iso_bytes ? per_cu_iso : per_cu_stream;
     const uint64_t slots = (uint64_t)per_cu * (uint64_t)cus, n_pos = r1 - r0;
     const uint64_t reach = iso_bytes && iso_bytes < window ? iso_bytes : window;
-    // isolated records are all alike: long segments; otherwise kIdxSegCap, or half of it while that still
-    // leaves the machine no more than two fillings (the tail of the last filling then runs on emptier CUs)
-    uint64_t cap = reach <= 4096 ? 8ull * kIdxSegCap : kIdxSegCap;
-    if (reach > 4096 && n_pos * ny <= slots * kIdxSegCap) cap = kIdxSegCap / 2;
+    // Every position costs the same whatever the data (no walk depends on it), so the waves of a filling end together
+    // and long segments are best: a segment of 768 Ki positions walks 1.08 of them, one of 256 Ki 1.25 (2.26 ms
+    // against 2.63 per 256 MiB and three key lengths).
+    const uint64_t seg_cap = cap_env > 0 ? (uint64_t)cap_env << 10 : kIdxSegCap;
+    const uint64_t cap = reach <= 4096 ? (2048ull << 10) : seg_cap;
     // whole fillings: as many as segments of `cap` need, and the segments then as long as those fillings allow
     // (a twentieth over a whole number of fillings stretches the segments instead of adding a filling)
     const uint64_t fillings = (n_pos * ny + slots * cap * 19 / 20) / (slots * cap);
@@ -762,8 +851,12 @@ hipError_t launch_index(const uint8_t *data, uint64_t n_view, uint64_t r0, uint6
     seg_len = (seg_len + kIdxSpan - 1) & ~(uint64_t)(kIdxSpan - 1);
     seg_len = seg_len < kIdxSegMin ? kIdxSegMin : seg_len;
     const uint64_t nseg = (n_pos + seg_len - 1) / seg_len;
-    hipLaunchKernelGGL(k_index_r, dim3((uint32_t)nseg, ny), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window, set,
-                       base, status, iso_first, iso_bytes, (uint32_t)seg_len);
+    if (iso_bytes)
+        hipLaunchKernelGGL(k_index_r<true>, dim3((uint32_t)nseg, ny), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window,
+                           set, base, status, iso_first, iso_bytes, (uint32_t)seg_len);
+    else
+        hipLaunchKernelGGL(k_index_r<false>, dim3((uint32_t)nseg, ny), dim3(64), 0, s, data, n_view, r0, r1, far_lo, window,
+                           set, base, status, iso_first, iso_bytes, (uint32_t)seg_len);
     return hipGetLastError();
 }
 
