@@ -175,6 +175,21 @@ int zg_decompress_batch_device(zg_ctx *ctx, const void *d_in, const uint64_t *d_
                                void *d_out, const uint64_t *d_out_offsets, uint64_t *d_out_len,
                                uint32_t *d_status);
 
+/* zlib::decompress (src/decompress.rs:34-88; its loop over blocks :97-118) for ONE
+ * large stream of this library, with all blocks decoded at once.  A DEFLATE
+ * stream does not say where its blocks begin, so a decoder normally goes
+ * through them one after the other; the caller passes what zg_last_block_offsets
+ * reported after compressing: bit_offsets[i] (host memory) = bit offset of block
+ * i, n_blocks = ceil(n / chunk_bytes) (1 for n = 0), n = the length of the
+ * uncompressed data (block i inflates to its bytes [i * chunk_bytes, ...)).
+ * chunk_bytes must be 32768 or more (ZG_ERR_UNSUPPORTED otherwise) and the blocks
+ * Dynamic or Fixed.  d_stream / d_out are device pointers; d_out needs n bytes.
+ * A stream that does not fit the description, or is corrupt, or fails its
+ * Adler-32: ZG_ERR_DATA (zg_last_error says what and in which block).  Scratch:
+ * 2 bytes per byte of output. */
+int zg_decompress_blocks_device(zg_ctx *ctx, const void *d_stream, size_t stream_bytes, const uint64_t *bit_offsets,
+                                size_t n_blocks, size_t chunk_bytes, void *d_out, size_t n);
+
 /* ---- sharded compress: one rank of a multi-GPU job ----
  * A rank owns `n` input bytes (a whole number of chunks unless it is the last
  * rank) and sees `halo` (<= 32768) bytes of the input that precede them:

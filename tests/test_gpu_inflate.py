@@ -78,3 +78,73 @@ def test_errors_of_the_reference(za):
     fails(bytes([0x78, 0x01, 0x4B, 0x04]), "input ends")             # body cut before the end-of-block symbol
     # a match that reaches before the start of the output (fixed block: length 3, distance 1, nothing written yet)
     fails(bytes([0x78, 0x01, 0x03, 0x02, 0x00, 0x00, 0x00, 0x00, 0x01]), "")
+
+
+def _blocks_round_trip(za, data, chunk, strategy):
+    """compress on the device, then inflate all blocks at once from the block offsets the compressor reports"""
+    import torch
+    n = len(data)
+    d_in = torch.frombuffer(bytearray(data) or bytearray(1), dtype=torch.uint8).cuda()
+    cap = za.compress_bound(n, strategy, chunk_bytes=chunk)
+    d_z = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    ctx = za.default_context()
+    zn = za.compress_device(d_in.data_ptr(), n, d_z.data_ptr(), cap, strategy, chunk_bytes=chunk, ctx=ctx)
+    offs = za.last_block_offsets(ctx=ctx)
+    d_out = torch.zeros(max(1, n), dtype=torch.uint8, device="cuda")
+    za.decompress_blocks_device(d_z.data_ptr(), zn, offs, chunk, d_out.data_ptr(), n, ctx=ctx)
+    return d_z[:zn].cpu().numpy().tobytes(), offs, d_out[:n].cpu().numpy().tobytes()
+
+
+@pytest.mark.parametrize("strategy", ["Dynamic", "Fixed"])
+def test_all_blocks_of_a_stream_at_once(za, strategy):
+    """zg_decompress_blocks_device: every block of a multi-block stream decoded by a wave of its own, matches that
+    reach back into the block before resolved afterwards; the result must be the input (and what system zlib makes
+    of the same stream, decoding block after block as src/decompress.rs:97-118 does)."""
+    st = getattr(za.Strategy, strategy)
+    rng = random.Random(31)
+    period = bytes(rng.randrange(256) for _ in range(40_000))  # matches 40 000 back: across every seam of 32 KiB chunks
+    runs = b"".join(bytes([rng.randrange(4)]) * rng.randint(1, 700) for _ in range(3000))
+    cases = [(za.corpus("mixed", (5 << 20) + 12345, seed=41), 1 << 20), (za.corpus("text", 700_001, seed=42), 1 << 16),
+             (za.corpus("text", 300_000, seed=43), 32768), (period[:30_000] * 12, 32768), (period[:20_000] * 9, 65536),
+             (runs, 32768), (bytes(300_000), 65536), (za.corpus("binary", 3 << 16, seed=44), 1 << 16),
+             (za.corpus("random", 200_000, seed=45), 65536), (za.corpus("text", 32768, seed=46), 32768),
+             (za.corpus("text", 1000, seed=47), 1 << 20), (b"", 1 << 20), (b"a", 32768)]
+    for data, chunk in cases:
+        stream, offs, got = _blocks_round_trip(za, data, chunk, st)
+        assert len(offs) == max(1, -(-len(data) // chunk))
+        assert got == data, (strategy, len(data), chunk)
+        assert sysz.decompress(stream) == data
+
+
+def test_all_blocks_at_once_refuses_what_does_not_fit(za):
+    import torch
+    data = za.corpus("text", 200_000, seed=51)
+    chunk = 65536
+    stream, offs, got = _blocks_round_trip(za, data, chunk, za.Strategy.Dynamic)
+    assert got == data
+    ctx = za.default_context()
+    d_out = torch.zeros(len(data), dtype=torch.uint8, device="cuda")
+
+    def run(s, o, n=len(data), ch=chunk):
+        d_z = torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda()
+        za.decompress_blocks_device(d_z.data_ptr(), len(s), o, ch, d_out.data_ptr(), n, ctx=ctx)
+
+    run(stream, offs)  # the baseline passes
+    assert d_out.cpu().numpy().tobytes() == data
+    for bad in ([offs[0]] + [o + 1 for o in offs[1:]], offs[:1] + [offs[1] - 3] + offs[2:]):  # blocks do not begin there
+        with pytest.raises(za.ZgError) as e:
+            run(stream, bad)
+        assert e.value.code == -8
+    for at in (len(stream) // 2, 40, len(stream) - 2):  # a flipped bit in a block / in the Adler-32
+        broken = bytearray(stream)
+        broken[at] ^= 0x10
+        with pytest.raises(za.ZgError) as e:
+            run(bytes(broken), offs)
+        assert e.value.code == -8
+    with pytest.raises(za.ZgError) as e:  # header: CM is not 8 (src/decompress.rs:44-46)
+        run(b"\x77" + stream[1:], offs)
+    assert e.value.code == -8
+    for kw in (dict(n=len(data) + chunk), dict(ch=16384), dict(o=offs[:-1])):  # arguments that contradict each other
+        with pytest.raises(za.ZgError) as e:
+            run(stream, kw.pop("o", offs), **kw)
+        assert e.value.code in (-1, -6)

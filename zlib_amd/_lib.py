@@ -19,7 +19,7 @@ ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_I
 SYMBOLS = [
     "zg_init", "zg_destroy", "zg_strerror", "zg_last_error", "zg_free", "zg_compress", "zg_compress_bound",
     "zg_compress_device", "zg_compress_multi", "zg_compress_stream", "zg_compress_file", "zg_last_block_offsets", "zg_compress_batch", "zg_compress_batch_bound", "zg_compress_batch_device",
-    "zg_decompress", "zg_decompress_batch", "zg_decompress_batch_device", "zg_shard_begin", "zg_shard_finish", "zg_adler32_combine", "zg_adler32",
+    "zg_decompress", "zg_decompress_batch", "zg_decompress_batch_device", "zg_decompress_blocks_device", "zg_shard_begin", "zg_shard_finish", "zg_adler32_combine", "zg_adler32",
     "zg_adler32_device", "zg_adler32_device_noalloc", "zg_lz77", "zg_huffman_from_tokens", "zg_profile_enable", "zg_profile_reset",
     "zg_profile_count", "zg_profile_get", "zg_corpus_fill",
 ]
@@ -92,6 +92,7 @@ def _declare(L):
     f("zg_decompress_batch", C.c_int, vp, C.c_char_p, C.POINTER(sz), sz, C.POINTER(C.POINTER(C.c_uint8)),
       C.POINTER(C.POINTER(sz)))
     f("zg_decompress_batch_device", C.c_int, vp, vp, vp, sz, vp, vp, vp, vp)
+    f("zg_decompress_blocks_device", C.c_int, vp, vp, sz, C.POINTER(C.c_uint64), sz, sz, vp, sz)
     f("zg_shard_begin", C.c_int, vp, vp, sz, sz, C.c_int, C.POINTER(Opts), C.c_int, C.POINTER(ShardInfo))
     f("zg_shard_finish", C.c_int, vp, C.c_uint64, C.c_int, C.c_int, C.c_uint32, vp, sz, C.POINTER(sz))
     f("zg_adler32_combine", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64)

@@ -265,6 +265,16 @@ def decompress_batch(streams: Sequence[bytes], *, ctx: Optional[Context] = None)
         _lib.lib().zg_free(out_offs)
 
 
+def decompress_blocks_device(d_stream: int, stream_bytes: int, bit_offsets: Sequence[int], chunk_bytes: int, d_out: int,
+                             n: int, *, ctx: Optional[Context] = None) -> None:
+    """zlib::decompress of one large stream of this library with every block decoded at once: `bit_offsets` is what
+    last_block_offsets() returned after compressing, `n` the length of the uncompressed data; device pointers."""
+    ctx = ctx or default_context()
+    offs = (C.c_uint64 * max(1, len(bit_offsets)))(*bit_offsets)
+    _check(_lib.lib().zg_decompress_blocks_device(ctx.handle, d_stream, stream_bytes, offs, len(bit_offsets), chunk_bytes,
+                                                  d_out, n), ctx)
+
+
 def compress_batch_bound(stride: int, n_records: int, strategy: Strategy = Strategy.Dynamic) -> int:
     return _lib.lib().zg_compress_batch_bound(stride, n_records, int(strategy))
 

@@ -84,7 +84,7 @@ struct zg_ctx {
     hipStream_t copy = nullptr;  // uploads of host input, overlapped with the kernels on `stream`
     std::mutex mu;
     std::string err;
-    DevBuf block_off_all, walk_exit, walk_chunk, shard_buf, far, next, far4, next4, far3, next3, open_list, open_far, open_cnt, rec_len, rec_off, inf_off, inf_len, inf_status, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
+    DevBuf inf_units, inf_win, block_off_all, walk_exit, walk_chunk, shard_buf, far, next, far4, next4, far3, next3, open_list, open_far, open_cnt, rec_len, rec_off, inf_off, inf_len, inf_status, match, tokens, ntok, freq, tab, hdr, hdr_bits, block_bits, bit_off, tile_bits, adler_part,
         scalars, stage_in, stage_out, misc, flag, sub_exit, sub_exit2, merged, tile_cnt, adler_blk;
     // shard state kept between zg_shard_begin and zg_shard_finish
     bool shard_active = false;
@@ -588,7 +588,7 @@ void zg_destroy(zg_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf *bufs[] = {&c->block_off_all, &c->walk_exit, &c->walk_chunk, &c->shard_buf, &c->far, &c->next, &c->far4, &c->next4, &c->far3, &c->next3, &c->open_list, &c->open_far, &c->open_cnt, &c->rec_len, &c->rec_off, &c->inf_off, &c->inf_len, &c->inf_status, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
+    DevBuf *bufs[] = {&c->inf_units, &c->inf_win, &c->block_off_all, &c->walk_exit, &c->walk_chunk, &c->shard_buf, &c->far, &c->next, &c->far4, &c->next4, &c->far3, &c->next3, &c->open_list, &c->open_far, &c->open_cnt, &c->rec_len, &c->rec_off, &c->inf_off, &c->inf_len, &c->inf_status, &c->match, &c->tokens, &c->ntok, &c->freq, &c->tab, &c->hdr, &c->hdr_bits,
                       &c->block_bits, &c->bit_off, &c->tile_bits, &c->adler_part, &c->scalars, &c->stage_in,
                       &c->stage_out, &c->misc, &c->flag, &c->sub_exit, &c->sub_exit2, &c->merged, &c->tile_cnt,
                       &c->adler_blk};
@@ -983,6 +983,68 @@ int zg_decompress_batch(zg_ctx *ctx, const uint8_t *in, const size_t *offsets, s
     for (size_t i = 0; i <= n_streams; i++) ho[i] = (size_t)ooff[i];
     *out = h;
     *out_offsets = ho;
+    return ZG_OK;
+}
+
+// One stream of this library, every block by a wave of its own (zg_inflate.hip, k_inflate_blocks).
+int zg_decompress_blocks_device(zg_ctx *ctx, const void *d_stream, size_t stream_bytes, const uint64_t *bit_offsets,
+                                size_t n_blocks, size_t chunk_bytes, void *d_out, size_t n) {
+    int rc = 0;
+    zg_ctx *c = resolve(ctx, &rc);
+    if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
+    if (!d_stream || !bit_offsets || n_blocks < 1 || n_blocks > 0xFFFFFFF0ull || (!d_out && n) || stream_bytes < 6)
+        return ZG_ERR_ARG;
+    if (chunk_bytes < kMaxWindow) return ZG_ERR_UNSUPPORTED;  // a block's window must lie in the one block before it
+    const size_t want_blocks = n == 0 ? 1 : (n + chunk_bytes - 1) / chunk_bytes;
+    if (want_blocks != n_blocks || bit_offsets[0] != 16) return ZG_ERR_ARG;
+    for (size_t i = 1; i < n_blocks; i++)
+        if (bit_offsets[i] <= bit_offsets[i - 1] || bit_offsets[i] >= (uint64_t)(stream_bytes - 4) * 8) return ZG_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    const uint8_t *in = static_cast<const uint8_t *>(d_stream);
+    uint8_t edge[6];  // header and trailer (src/decompress.rs:37-69, 74-87)
+    HIPCHK(hipMemcpy(edge, in, 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(edge + 2, in + stream_bytes - 4, 4, hipMemcpyDeviceToHost));
+    uint32_t hst = INF_OK;
+    if ((edge[0] & 15u) != 8u) hst = INF_BAD_METHOD;
+    else if ((edge[0] >> 4) > 7u) hst = INF_BAD_WINDOW;
+    else if ((edge[0] * 256u + edge[1]) % 31u != 0u) hst = INF_BAD_FCHECK;
+    else if ((edge[1] >> 5) & 1u) hst = INF_PRESET_DICT;
+    if (hst != INF_OK) {
+        c->err = inflate_message(hst);
+        return ZG_ERR_DATA;
+    }
+    HIPCHK(c->inf_units.ensure((n + 64) * sizeof(uint16_t)));
+    HIPCHK(c->inf_win.ensure(n_blocks * (size_t)kMaxWindow));
+    HIPCHK(c->inf_off.ensure(n_blocks * sizeof(uint64_t)));
+    HIPCHK(c->inf_status.ensure((n_blocks + 2) * sizeof(uint32_t)));
+    rc = init_scalars(c, 0);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->inf_off.p, bit_offsets, n_blocks * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    LAUNCH(K_INFLATE, launch_inflate_blocks(in, stream_bytes, c->inf_off.as<uint64_t>(), (uint32_t)n_blocks, chunk_bytes, n,
+                                            c->inf_units.as<uint16_t>(), c->inf_win.as<uint8_t>(),
+                                            static_cast<uint8_t *>(d_out), c->inf_status.as<uint32_t>(), c->stream));
+    rc = run_adler(c, static_cast<const uint8_t *>(d_out), n);
+    if (rc) return rc;
+    std::vector<uint32_t> st(n_blocks + 2, 0);
+    Scalars h;
+    HIPCHK(hipMemcpyAsync(st.data(), c->inf_status.p, (n_blocks + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&h, c->scalars.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->prof) prof_collect(c);
+    const uint64_t end_bit = (uint64_t)st[n_blocks] | ((uint64_t)st[n_blocks + 1] << 32);
+    st.resize(n_blocks);
+    rc = inflate_verdict(c, st);
+    if (rc) return rc;
+    if (((end_bit + 7) >> 3) + 4 != stream_bytes) {
+        c->err = "the last block does not end where the Adler-32 begins";
+        return ZG_ERR_DATA;
+    }
+    const uint32_t want = ((uint32_t)edge[2] << 24) | ((uint32_t)edge[3] << 16) | ((uint32_t)edge[4] << 8) | edge[5];
+    if (want != ((h.adler[1] << 16) | h.adler[0])) {
+        c->err = inflate_message(INF_BAD_CHECKSUM);
+        return ZG_ERR_DATA;
+    }
     return ZG_OK;
 }
 
