@@ -12,10 +12,16 @@ many GPUs take part (scaling "strong": the corpus stays 8 GiB, N GPUs take
 8/N GiB each).  The other workloads keep a fixed number of bytes per GPU
 (scaling "weak").  The corpus is cut into contiguous runs of 1 MiB chunks, one
 run per rank (each rank also sees the 32 KiB of input before its run); the
-ranks exchange their block bit totals and Adler-32 parts with one all_gather
-over RCCL, pack their blocks at the right bit phase and send the bytes to
-rank 0 (zlib_amd/sharding.py).  PyTorch is used for device memory, streams and
-torch.distributed only.
+ranks compress their runs pass by pass; after every pass one small all_gather
+over RCCL says how many bytes each rank has finished, and those bytes travel
+to rank 0 while the next pass's kernels run; rank 0 merges the runs at their
+bit offsets (zlib_amd/sharding.py).  PyTorch is used for device memory, streams
+and torch.distributed only.
+
+On one GPU with the default workload the same JSON line carries, under
+"other_configs", short runs of the other single-GPU configurations (64 MiB of
+text, 4 GiB of stored blocks, 4 GiB of 4 KiB records) and of the headline
+workload through the shard calls.
 """
 from __future__ import annotations
 
@@ -58,6 +64,7 @@ def parse_args():
     ap.add_argument("--workload", default=os.environ.get("ZG_BENCH_WORKLOAD", "mixed8g"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="the headline workload only")
     return ap.parse_args()
 
 
@@ -120,7 +127,7 @@ def verify_stream(za, stream, kind, seed, total):
     return pos + len(tail) == total and not tail and d.eof and not d.unused_data
 
 
-TRAFFIC_FILE = "r2_traffic.json"
+TRAFFIC_FILE = "r3_traffic.json"
 
 
 def measured_traffic(workload, kernel, live_avg_ms):
@@ -182,6 +189,162 @@ def cpu_baseline(za, kind, seed, total, chunk, torch=None, ctx=None, device=None
     }
 
 
+def device_round_trip(torch, za, ctx, d_stream, stream_bytes, offsets, chunk, d_in, n, device):
+    """Inflates the stream on the device, every block at once (zg_decompress_blocks_device: the library's own inflate,
+    which also checks the Adler-32), and compares with the input there.  (ok, milliseconds of the inflate)."""
+    back = torch.empty(n + 64, dtype=torch.uint8, device=device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    za.decompress_blocks_device(d_stream.data_ptr(), stream_bytes, offsets, chunk, back.data_ptr(), n, ctx=ctx)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    ok = bool(torch.equal(back[:n], d_in[:n]))
+    del back
+    return ok, ms
+
+
+def run_workload(name, steps, warmup, env, verify=True, shard_path=False, exchange="overlapped"):
+    """Uploads the workload's corpus, times `steps` passes of the hot path over it and checks the result.  Returns a
+    dictionary of what was measured (on every rank; the whole-job figures are valid on rank 0)."""
+    torch, dist, za, sharding = env["torch"], env["dist"], env["za"], env["sharding"]
+    rank, world, device, ctx = env["rank"], env["world"], env["device"], env["ctx"]
+    kind, per_gpu, chunk, seed, strat_name = WORKLOADS[name]
+    strong = name in STRONG
+    total = per_gpu if strong else per_gpu * world  # bytes of the whole job
+    start, n, halo = sharding.plan_shards(total, chunk, world)[rank]
+    d_in = upload_corpus(torch, za, kind, seed, start - halo, halo + n, device)
+    strategy = getattr(za.Strategy, strat_name)
+    if world > 1 and strat_name != "Dynamic":
+        raise SystemExit("the sharded path covers Dynamic/Fixed blocks only")
+    batch = kind == "records"
+    final = d_off = d_out = None
+    bound = lambda m: za.compress_bound(m, strategy, chunk_bytes=chunk)
+    if batch:
+        # records are independent streams: every rank compresses its own records, nothing is exchanged
+        n_rec = n // chunk
+        cap = za.compress_batch_bound(chunk, n_rec, strategy)
+        d_out = torch.empty(cap, dtype=torch.uint8, device=device)
+        d_off = torch.zeros(n_rec + 1, dtype=torch.int64, device=device)
+
+        def step():
+            return za.compress_batch_device(d_in.data_ptr() + halo, chunk, 0, n_rec, d_out.data_ptr(), cap,
+                                            d_off.data_ptr(), strategy, ctx=ctx)
+    elif world == 1 and not shard_path:
+        cap = bound(n)
+        d_out = torch.empty(cap, dtype=torch.uint8, device=device)
+
+        def step():
+            return za.compress_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, strategy, chunk_bytes=chunk, ctx=ctx)
+    elif exchange == "overlapped":
+        # every rank's run in passes of SHARD_PASS bytes; the bytes of pass k travel while pass k + 1 is computed
+        packed = torch.empty(bound(n) + 8, dtype=torch.uint8, device=device)
+        stages = None
+        if rank == 0:
+            final = torch.empty(bound(total) + 8, dtype=torch.uint8, device=device)
+            plan = sharding.plan_shards(total, chunk, world)
+            stages = [None] + [torch.empty(sharding.stage_bytes(plan[r][1], bound), dtype=torch.uint8, device=device)
+                               for r in range(1, world)]
+        engine = sharding.HipPieceEngine(ctx, d_in.data_ptr(), halo, n, strategy, chunk, SHARD_PASS, packed)
+        scratch = {}
+        d = dist if world > 1 else sharding.SingleRank
+
+        def step():
+            return sharding.compress_sharded_overlapped(engine, d, torch, rank, world, device, final=final,
+                                                        stages=stages, scratch=scratch)
+    else:
+        d_out = torch.empty(bound(n) + 8, dtype=torch.uint8, device=device)
+        if rank == 0:
+            final = torch.empty(bound(total) + 8, dtype=torch.uint8, device=device)
+        engine = sharding.HipEngine(ctx, d_in.data_ptr(), halo, n, strategy, chunk, d_out)
+        scratch = {}
+
+        def step():
+            return sharding.compress_sharded(engine, dist, torch, rank, world, device, final=final, scratch=scratch)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        out_n = step()
+    ctx.profile(True)
+    ctx.profile_reset()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out_n = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = ctx.profile_get()
+    ctx.profile(False)
+
+    verified, inflate_ms = None, None
+    if batch:
+        if world > 1:  # whole-job output size
+            t = torch.tensor([out_n], dtype=torch.int64, device=device)
+            dist.all_reduce(t)
+            out_n_total = int(t.item())
+        else:
+            out_n_total = out_n
+        if rank == 0 and verify:
+            import zlib as sysz
+            off = d_off.cpu().tolist()
+            verified = off[-1] == out_n
+            for i in range(0, n_rec, max(1, n_rec // 2000)):  # a spread sample of this rank's records
+                got = sysz.decompress(d_out[off[i]:off[i + 1]].cpu().numpy().tobytes())
+                verified = verified and got == za.corpus(kind, chunk, seed=seed, offset=start + i * chunk)
+            if not verified:
+                raise SystemExit("record round trip through system zlib FAILED")
+        out_n = out_n_total
+    elif rank == 0 and verify:
+        d_stream = final if final is not None else d_out
+        if world == 1 and strat_name != "Raw":
+            offsets = za.last_block_offsets(ctx=ctx)
+            if shard_path:
+                offsets = [o + sharding.ZLIB_HEADER_BITS for o in offsets]  # a run's offsets count from its first block
+            ok, inflate_ms = device_round_trip(torch, za, ctx, d_stream, out_n, offsets, chunk, d_in[halo:], n, device)
+            if not ok:
+                raise SystemExit("round trip through the library's inflate FAILED")
+        if verify == "full":
+            stream = d_stream[:out_n].cpu().numpy()
+            verified = verify_stream(za, stream, kind, seed, total)
+            del stream
+            if not verified:
+                raise SystemExit("round trip through system zlib FAILED")
+    res = {"name": name, "kind": kind, "strategy": strat_name, "chunk": chunk, "seed": seed, "total": total, "n": n,
+           "strong": strong, "batch": batch, "dt": dt, "steps": steps, "out_n": out_n, "prof": prof,
+           "verified": verified, "inflate_ms": inflate_ms}
+    del d_in, d_out, final
+    torch.cuda.empty_cache()
+    return res
+
+
+def kernel_roofline(res, workload_for_traffic, world):
+    """The dominant kernel of the step by accumulated event time, priced on algorithmic bytes."""
+    prof, steps = res["prof"], res["steps"]
+    kname, (kms, kn) = max(((k, v) for k, v in prof.items() if k != "misc"), key=lambda kv: kv[1][0])
+    k_avg_ms = kms / max(1, kn)
+    launches_per_step = kn / steps
+    ratio = res["out_n"] / res["total"]
+    bytes_per_launch = res["n"] * (1.0 + ratio) / max(1.0, launches_per_step)  # this rank's share
+    achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9
+    traffic, stale = measured_traffic(workload_for_traffic, kname, k_avg_ms) if world == 1 else (None, None)
+    return {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": stale,
+            "kernel_avg_ms": k_avg_ms, "launches_per_step": launches_per_step,
+            "algorithmic_bytes_per_launch": bytes_per_launch}
+
+
+SHARD_PASS = 128 << 20  # input bytes per pass of a rank's run when the exchange runs beside the kernels
+OTHER_CONFIGS = ("text64m", "raw4g", "records4g")  # the other single-GPU configurations, measured after the headline
+
+
 def main():
     args = parse_args()
     import torch
@@ -190,7 +353,6 @@ def main():
     import zlib_amd as za
     from zlib_amd import sharding
 
-    kind, per_gpu, chunk, seed, strat_name = WORKLOADS[args.workload]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -207,107 +369,35 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
-
-    strong = args.workload in STRONG
-    total = per_gpu if strong else per_gpu * world  # bytes of the whole job
-    per_gpu = total // world
     ctx = za.Context(dev_index)
-    start, n, halo = sharding.plan_shards(total, chunk, world)[rank]
-    d_in = upload_corpus(torch, za, kind, seed, start - halo, halo + n, device)
-    strategy = getattr(za.Strategy, strat_name)
-    final = None
-    if world > 1 and strat_name != "Dynamic":
-        raise SystemExit("the sharded path covers Dynamic/Fixed blocks only")
+    env = {"torch": torch, "dist": dist, "za": za, "sharding": sharding, "rank": rank, "world": world,
+           "device": device, "ctx": ctx}
+    exchange = os.environ.get("ZG_BENCH_EXCHANGE", "overlapped")  # "serial": exchange after all kernels (compress_sharded)
 
-    batch = kind == "records"
-    d_off = None
-    if batch:
-        # records are independent streams: every rank compresses its own records, nothing is exchanged
-        n_rec = n // chunk
-        cap = za.compress_batch_bound(chunk, n_rec, strategy)
-        d_out = torch.empty(cap, dtype=torch.uint8, device=device)
-        d_off = torch.zeros(n_rec + 1, dtype=torch.int64, device=device)
-
-        def step():
-            return za.compress_batch_device(d_in.data_ptr() + halo, chunk, 0, n_rec, d_out.data_ptr(), cap,
-                                            d_off.data_ptr(), strategy, ctx=ctx)
-    elif world == 1:
-        cap = za.compress_bound(n, strategy, chunk_bytes=chunk)
-        d_out = torch.empty(cap, dtype=torch.uint8, device=device)
-
-        def step():
-            return za.compress_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, strategy, chunk_bytes=chunk, ctx=ctx)
-    else:
-        cap = za.compress_bound(n, strategy, chunk_bytes=chunk) + 8
-        d_out = torch.empty(cap, dtype=torch.uint8, device=device)
-        if rank == 0:
-            final = torch.empty(za.compress_bound(total, strategy, chunk_bytes=chunk) + 8, dtype=torch.uint8,
-                                device=device)
-        engine = sharding.HipEngine(ctx, d_in.data_ptr(), halo, n, strategy, chunk, d_out)
-        scratch = {}
-
-        def step():
-            return sharding.compress_sharded(engine, dist, torch, rank, world, device, final=final, scratch=scratch)
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        out_n = step()
-    ctx.profile(True)
-    ctx.profile_reset()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out_n = step()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    prof = ctx.profile_get()
-    ctx.profile(False)
-
-    verified = None
-    if batch:
-        if world > 1:  # whole-job output size
-            t = torch.tensor([out_n], dtype=torch.int64, device=device)
-            dist.all_reduce(t)
-            out_n_total = int(t.item())
-        else:
-            out_n_total = out_n
-        if rank == 0 and not args.no_verify:
-            import zlib as sysz
-            off = d_off.cpu().tolist()
-            verified = off[-1] == out_n
-            for i in range(0, n_rec, max(1, n_rec // 2000)):  # a spread sample of this rank's records
-                got = sysz.decompress(d_out[off[i]:off[i + 1]].cpu().numpy().tobytes())
-                verified = verified and got == za.corpus(kind, chunk, seed=seed, offset=start + i * chunk)
-            if not verified:
-                raise SystemExit("record round trip through system zlib FAILED")
-        out_n = out_n_total
-    elif rank == 0 and not args.no_verify:
-        stream = (final if world > 1 else d_out)[:out_n].cpu().numpy()
-        verified = verify_stream(za, stream, kind, seed, total)
-        del stream
-        if not verified:
-            raise SystemExit("round trip through system zlib FAILED")
+    res = run_workload(args.workload, args.steps, args.warmup, env, verify=False if args.no_verify else "full",
+                       exchange=exchange)
+    kind, chunk, seed, strat_name = res["kind"], res["chunk"], res["seed"], res["strategy"]
+    total, batch, strong, out_n = res["total"], res["batch"], res["strong"], res["out_n"]
+    per_gpu = total // world
 
     if rank == 0:
-        ms_step = dt / args.steps * 1e3
-        value = total * args.steps / dt / 1e9
+        ms_step = res["dt"] / args.steps * 1e3
+        value = total * args.steps / res["dt"] / 1e9
         ratio = out_n / total
-        # dominant kernel of the step by accumulated event time
-        kname, (kms, kn) = max(((k, v) for k, v in prof.items() if k != "misc"), key=lambda kv: kv[1][0])
-        k_avg_ms = kms / max(1, kn)
-        launches_per_step = kn / args.steps
-        bytes_per_launch = n * (1.0 + ratio) / max(1.0, launches_per_step)  # this rank's share
-        achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9
-        traffic, traffic_stale = measured_traffic(args.workload, kname, k_avg_ms) if world == 1 else (None, None)
+        roof = kernel_roofline(res, args.workload, world)
+        roof["traffic_note"] = ("HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (separate rocprofv3 --pmc passes over "
+                                f"this command, profiles/{TRAFFIC_FILE}); null if not collected for this workload; "
+                                "stale: the kernel's duration has moved by more than a fifth since the counters were taken")
+        roof["note"] = "algorithmic bytes = input bytes read once + compressed bytes written once"
+        if world == 1:
+            par = "single GPU"
+        elif batch:
+            par = "records sharded over ranks, no exchange"
+        elif exchange == "overlapped":
+            par = (f"chunks sharded over ranks; per pass of {SHARD_PASS >> 20} MiB one all_gather of piece sizes and the "
+                   "pass's bytes sent to rank 0 beside the next pass's kernels; rank 0 merges the runs at their bit offsets")
+        else:
+            par = "chunks sharded over ranks; all_gather of bit totals + payload send to rank 0"
         line = {
             "metric": f"compress input GB/s ({strat_name})", "value": value, "unit": "GB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -318,21 +408,36 @@ def main():
                                     f"{chunk >> 10} KiB chunks with 32 KiB window, {world} MI355X"),
                        "name": args.workload, "chunk_bytes": chunk,
                        "total_bytes": total, "compressed_bytes": out_n, "ratio": ratio,
-                       "round_trip_system_zlib": verified,
-                       "parallelism": ("records sharded over ranks, no exchange" if batch else
-                                       "chunks sharded over ranks; all_gather of bit totals + payload send to rank 0")
-                       if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale,
-                         "traffic_note": "HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (separate rocprofv3 --pmc "
-                                         f"passes over this command, profiles/{TRAFFIC_FILE}); null if not collected "
-                                         "for this workload; stale: the kernel's duration has moved by more than a "
-                                         "fifth since the counters were taken",
-                         "kernel_avg_ms": k_avg_ms, "launches_per_step": launches_per_step,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "algorithmic bytes = input bytes read once + compressed bytes written once"},
-            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1]},
+                       "round_trip_system_zlib": res["verified"],
+                       "round_trip_on_device": None if res["inflate_ms"] is None else True,
+                       "inflate_on_device_ms": res["inflate_ms"],
+                       "parallelism": par},
+            "roofline": roof,
+            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in res["prof"].items() if v[1]},
         }
+    headline = args.workload == "mixed8g"
+    if world == 1 and headline and not args.no_others:
+        # the other single-GPU configurations and the shard calls on one rank, a few passes each
+        others = {}
+        for name in OTHER_CONFIGS:
+            r = run_workload(name, 3, 1, env, verify=not args.no_verify and ("full" if name != "records4g" else True))
+            roof = kernel_roofline(r, name, world)
+            others[name] = {"metric": f"compress input GB/s ({r['strategy']})", "value": r["total"] * r["steps"] / r["dt"] / 1e9,
+                            "unit": "GB/s", "ms_per_step": r["dt"] / r["steps"] * 1e3, "steps": r["steps"], "warmup": 1,
+                            "total_bytes": r["total"], "chunk_bytes": r["chunk"], "ratio": r["out_n"] / r["total"],
+                            "round_trip_system_zlib": r["verified"], "inflate_on_device_ms": r["inflate_ms"],
+                            "dominant_kernel": roof["kernel"], "kernel_avg_ms": roof["kernel_avg_ms"],
+                            "roofline_frac": roof["frac"], "traffic": roof["traffic"]}
+        r = run_workload(args.workload, 3, 1, env, verify=not args.no_verify, shard_path=True)
+        ms = r["dt"] / r["steps"] * 1e3
+        others["mixed8g_shard_calls"] = {
+            "what": f"the headline workload through zg_shard_open/next/merge/seal on one rank, passes of {SHARD_PASS >> 20} MiB "
+                    "(what a rank of a multi-GPU run executes, with nothing to exchange)",
+            "value": r["total"] * r["steps"] / r["dt"] / 1e9, "unit": "GB/s", "ms_per_step": ms, "steps": r["steps"],
+            "ms_over_compress_device": ms - ms_step, "compressed_bytes_equal": r["out_n"] == out_n,
+            "inflate_on_device_ms": r["inflate_ms"]}
+        line["other_configs"] = others
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and strat_name == "Dynamic" and not batch:
             line["cpu_baseline"] = cpu_baseline(za, kind, seed, total, chunk, torch, ctx, device)
         print(json.dumps(line), flush=True)

@@ -213,6 +213,36 @@ int zg_shard_begin(zg_ctx *ctx, const void *d_in, size_t halo, size_t n, int str
 int zg_shard_finish(zg_ctx *ctx, uint64_t base_bit, int first_rank, int last_rank, uint32_t adler,
                     void *d_out, size_t out_cap, size_t *out_bytes);
 uint32_t zg_adler32_combine(uint32_t adler1, uint32_t adler2, uint64_t len2);
+/* The same in pieces, for an exchange that runs beside the kernels.  zg_shard_open
+ * starts compressing the rank's chunks, one pass over the scratch buffers
+ * (batch_bytes of input) at a time, into d_packed (a device buffer of the
+ * CALLER's, 4-byte aligned, zg_compress_bound(n) + 8 bytes), from its bit 0
+ * on.  Every zg_shard_next call queues the kernels of the next pass, waits for
+ * the oldest unreported one and says which bytes of d_packed have become final
+ * with it -- bytes [byte_offset, byte_offset + n_bytes); the byte a pass ends in
+ * the middle of belongs to the next piece -- so that the caller can ship them
+ * while the GPU works on.  The piece with last != 0 ends the run and fills *info.
+ * The rank that assembles the stream merges every rank's bytes, in stream
+ * order, at the bit offset the totals give it (zg_shard_merge; first_run writes
+ * 78 01 in front, base_bit 16) and closes with zg_shard_seal (padding to a
+ * byte, Adler-32).  d_src / d_dst are 4-byte aligned device buffers; d_src must
+ * be readable up to the end of the word its last bit lies in, d_dst needs 8
+ * bytes beyond the last bit.  Merges on one ctx run in the order of the calls.
+ * No counterpart in the reference (src/compress.rs:51-86 is one call on one
+ * slice). */
+typedef struct zg_shard_piece {
+    uint64_t byte_offset; /* first byte of the piece, counted from d_packed             */
+    uint64_t n_bytes;     /* bytes of d_packed that are final from there on             */
+    uint64_t bits_so_far; /* bits of all blocks finished so far                        */
+    int last;             /* non-zero: the rank's last piece                            */
+} zg_shard_piece;
+int zg_shard_open(zg_ctx *ctx, const void *d_in, size_t halo, size_t n, int strategy, const zg_opts *opts,
+                  int last_rank, void *d_packed, size_t packed_cap);
+int zg_shard_next(zg_ctx *ctx, zg_shard_piece *piece, zg_shard_info *info);
+int zg_shard_merge(zg_ctx *ctx, const void *d_src, uint64_t n_bits, void *d_dst, size_t dst_cap, uint64_t base_bit,
+                   int first_run);
+int zg_shard_seal(zg_ctx *ctx, void *d_dst, size_t dst_cap, uint64_t end_bit, uint32_t adler, size_t *out_bytes);
+
 
 /* ---- zlib::adler::adler32(&[u8]) -> u32   (src/adler.rs:5-13) ---- */
 int zg_adler32(zg_ctx *ctx, const uint8_t *in, size_t n, uint32_t *out);

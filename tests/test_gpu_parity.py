@@ -420,6 +420,101 @@ def test_shard_api_assembles_the_single_gpu_stream(za, z, world, total, chunk):
     assert sysz.decompress(bytes(final)) == data
 
 
+@pytest.mark.parametrize("world,total,chunk,batch", [(3, (6 << 20) + 4321, 1 << 16, 1 << 19), (2, 300_000, 16384, 16384),
+                                                     (4, 3 << 20, 1 << 18, 1 << 20), (1, 1_000_000, 1 << 17, 1 << 18)])
+def test_shard_pieces_assemble_the_single_gpu_stream(za, z, world, total, chunk, batch):
+    """zg_shard_open / zg_shard_next for every rank's run (one after the other on this GPU), pass by pass; every
+    piece is copied away the moment it is reported, as an exchange that runs beside the kernels would, and the
+    copies -- not the rank's buffer as it is at the end -- are merged (zg_shard_merge) and sealed (zg_shard_seal)
+    on the first rank's context.  The result is the oracle's stream."""
+    import torch
+    from zlib_amd import sharding
+    data = za.corpus("mixed" if total > (1 << 20) else "text", total, seed=31)
+    whole = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    plan = sharding.plan_shards(total, chunk, world)
+    bound = lambda n: za.compress_bound(n, za.Strategy.Dynamic, chunk_bytes=chunk)
+    stages, infos, n_pieces, ctxs = [], [], [], []
+    for r, (start, n, halo) in enumerate(plan):
+        ctx = za.Context(0)
+        ctxs.append(ctx)
+        view = whole[start - halo:start + n].clone()
+        packed = torch.full((bound(n) + 8,), 0xEE, dtype=torch.uint8, device="cuda")
+        stage = torch.full((sharding.stage_bytes(n, bound),), 0xEE, dtype=torch.uint8, device="cuda")
+        eng = sharding.HipPieceEngine(ctx, view.data_ptr(), halo, n, za.Strategy.Dynamic, chunk, batch, packed)
+        eng.open(r == world - 1)
+        at = k = 0
+        while True:
+            off, nb, bits, last, ad = eng.next()
+            assert off == at and (bits // 8 == off + nb if not last else (bits + 7) // 8 == off + nb)
+            stage[off:off + nb].copy_(packed[off:off + nb])
+            at, k = at + nb, k + 1
+            if last:
+                break
+        assert k == -(-max(1, -(-n // chunk)) // max(1, batch // chunk))
+        torch.cuda.synchronize()
+        assert torch.equal(stage[:at], packed[:at]), "a piece changed after it had been reported"
+        n_pieces.append(k)
+        stages.append(stage)
+        infos.append((bits, ad, n))
+        blocks = za.last_block_offsets(ctx=ctx)
+        assert len(blocks) == max(1, -(-n // chunk)) and blocks[0] == 0 and all(a < b for a, b in zip(blocks, blocks[1:]))
+        with pytest.raises(za.ZgError):
+            eng.next()  # the run has ended
+    bases, end_bit, adler = sharding.stream_layout(infos)
+    final = torch.full(((end_bit + 7) // 8 + 4 + 16,), 0xEE, dtype=torch.uint8, device="cuda")
+    head = sharding.HipPieceEngine(ctxs[0], 0, 0, 0, za.Strategy.Dynamic, chunk, batch, None)
+    for r in range(world):
+        head.merge(stages[r], infos[r][0], final, bases[r], r == 0)
+    nb = head.seal(final, end_bit, adler)
+    got = final[:nb].cpu().numpy().tobytes()
+    _same(got, z.compress_chunked(data, z.DYNAMIC, chunk, fast=True), f"oracle, pieces per rank {n_pieces}")
+    assert sysz.decompress(got) == data
+    for c in ctxs:
+        c.close()
+
+
+def test_shard_pieces_through_the_assembly_logic_and_refusals(za, z):
+    """One rank through sharding.compress_sharded_overlapped (the calls a multi-GPU run makes, nothing to exchange);
+    what the piecewise calls refuse."""
+    import torch
+    from zlib_amd import sharding
+    total, chunk = (2 << 20) + 999, 1 << 17
+    data = za.corpus("mixed", total, seed=33)
+    d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    cap = za.compress_bound(total, za.Strategy.Dynamic, chunk_bytes=chunk) + 8
+    packed = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    final = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    ctx = za.Context(0)
+    eng = sharding.HipPieceEngine(ctx, d_in.data_ptr(), 0, total, za.Strategy.Dynamic, chunk, 1 << 19, packed)
+    for _ in range(2):
+        n = sharding.compress_sharded_overlapped(eng, sharding.SingleRank, torch, 0, 1, torch.device("cuda"),
+                                                 final=final, stages=[None])
+        _same(final[:n].cpu().numpy().tobytes(), z.compress_chunked(data, z.DYNAMIC, chunk, fast=True), "oracle")
+    with pytest.raises(za.ZgError):  # no run is open
+        za.shard_next(ctx=ctx)
+    with pytest.raises(za.ZgError):  # the packed buffer is too small
+        za.shard_open(d_in.data_ptr(), 0, total, za.Strategy.Dynamic, True, packed.data_ptr(), 1000, chunk_bytes=chunk, ctx=ctx)
+    with pytest.raises(za.ZgError):  # the first run begins behind the two header bytes
+        za.shard_merge(packed.data_ptr(), 100, final.data_ptr(), cap, 24, True, ctx=ctx)
+    with pytest.raises(za.ZgError):  # no room
+        za.shard_merge(packed.data_ptr(), 8 * 4096, final.data_ptr(), 4096, 16, True, ctx=ctx)
+    with pytest.raises(za.ZgError):
+        za.shard_seal(final.data_ptr(), 100, 8 * 100, 1, ctx=ctx)
+    # a whole-stream call on the same context still works afterwards
+    _same(za.compress(data, za.Strategy.Dynamic, chunk_bytes=chunk, ctx=ctx),
+          z.compress_chunked(data, z.DYNAMIC, chunk, fast=True), "after the refusals")
+    ctx.close()
+
+
+def test_several_devices_failing_call_leaves_nothing_behind(za, z):
+    """zg_compress_multi with a device that does not exist: the call fails as a whole, and the next one works."""
+    data = za.corpus("text", 400_000, seed=35)
+    with pytest.raises(za.ZgError):
+        za.compress_multi(data, [0, 4096], za.Strategy.Dynamic, chunk_bytes=1 << 16)
+    _same(za.compress_multi(data, [0, 0], za.Strategy.Dynamic, chunk_bytes=1 << 16),
+          z.compress_chunked(data, z.DYNAMIC, 1 << 16, fast=True), "after a failed call")
+
+
 def _record_cases(za):
     rng = random.Random(77)
     recs = [b"", b"a", b"abc", b"hello hello hello hello", bytes(4096), b"\x01" * 1000,

@@ -50,6 +50,121 @@ class OracleEngine:
         return len(raw)
 
 
+class OraclePieceEngine:
+    """What zg_shard_open / _next / _merge / _seal do on a GPU, restated with the oracle's blocks and Python integers:
+    a pass is `pass_chunks` blocks; after it the buffer holds all bits so far, of which the complete bytes are final."""
+
+    def __init__(self, data, start, n, chunk, pass_chunks):
+        self.data, self.start, self.n, self.chunk, self.pass_chunks = data, start, n, chunk, pass_chunks
+        self.packed = torch.zeros(n * 2 + 4096, dtype=torch.uint8)
+
+    def open(self, last_rank):
+        nchunks = max(1, -(-self.n // self.chunk))
+        c0 = self.start // self.chunk
+        self.blocks = []
+        for c in range(nchunks):
+            toks = zref.chunk_tokens(self.data, self.chunk, c0 + c, fast=True)
+            self.blocks.append(zref.write_block(toks, zref.DYNAMIC, last_rank and c == nchunks - 1))
+        self.acc = self.pos = self.at = self.reported = 0
+        self.packed.fill_(0xEE)  # stale bytes of an earlier call
+
+    def next(self):
+        assert self.at < len(self.blocks)
+        for blk, bits in self.blocks[self.at:self.at + self.pass_chunks]:
+            self.acc |= int.from_bytes(blk, "little") << self.pos
+            self.pos += bits
+        self.at = min(len(self.blocks), self.at + self.pass_chunks)
+        last = self.at == len(self.blocks)
+        raw = self.acc.to_bytes((self.pos + 7) // 8, "little")  # the unfinished byte is in the buffer, not in the piece
+        self.packed[self.reported:len(raw)] = torch.frombuffer(bytearray(raw[self.reported:]), dtype=torch.uint8)
+        done = len(raw) if last else self.pos // 8
+        off, self.reported = self.reported, done
+        ad = zref.adler32(self.data[self.start:self.start + self.n]) if last else None
+        return off, done - off, self.pos, last, ad
+
+    @staticmethod
+    def merge(src, n_bits, final, base_bit, first_run):
+        run = int.from_bytes(src[:(n_bits + 7) // 8].numpy().tobytes(), "little") & ((1 << n_bits) - 1)
+        if first_run:
+            assert base_bit == 16
+            final[0], final[1] = 0x78, 0x01
+        lo, ph = base_bit // 8, base_bit % 8
+        keep = int(final[lo]) & ((1 << ph) - 1) if ph else 0
+        raw = (keep | (run << ph)).to_bytes((ph + n_bits + 7) // 8, "little")
+        final[lo:lo + len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+
+    @staticmethod
+    def seal(final, end_bit, adler):
+        at = (end_bit + 7) // 8
+        final[at:at + 4] = torch.frombuffer(bytearray(adler.to_bytes(4, "big")), dtype=torch.uint8)
+        return at + 4
+
+
+def _piece_worker(rank, world, port, total, chunk, pass_chunks, q, piece=None):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if piece:
+        sharding.P2P_PIECE = piece
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        data = _corpus(total)
+        plan = sharding.plan_shards(total, chunk, world)
+        start, n, _halo = plan[rank]
+        eng = OraclePieceEngine(data, start, n, chunk, pass_chunks)
+        final = stages = None
+        if rank == 0:
+            final = torch.full((total * 2 + 4096,), 0xEE, dtype=torch.uint8)
+            stages = [None] + [torch.full((plan[r][1] * 2 + 4096,), 0xEE, dtype=torch.uint8) for r in range(1, world)]
+        scratch = {}
+        for _ in range(2):  # twice: scratch tensors and staging buffers are reused
+            length = sharding.compress_sharded_overlapped(eng, dist, torch, rank, world, torch.device("cpu"),
+                                                          final=final, stages=stages, scratch=scratch)
+        if rank == 0:
+            q.put(bytes(final[:length].numpy().tobytes()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total,chunk,pass_chunks,piece", [
+    (2, 150_000, 16384, 2, None),   # 5 chunks each way: ranks with 2 and 3 chunks, 1 and 2 passes
+    (2, 65536, 32768, 4, None),     # one pass per rank
+    (3, 100_000, 8192, 1, None),    # a pass per chunk: 4 or 5 passes per rank
+    (3, 100_000, 8192, 3, 1000),    # pieces travel in several point-to-point operations
+    (3, 20_000, 8192, 1, None),     # 3 chunks over 3 ranks, the last one short
+])
+def test_overlapped_assembly_equals_single_stream(world, total, chunk, pass_chunks, piece):
+    """The exchange that runs beside the kernels: per pass one all_gather of piece sizes and one send of the bytes
+    that pass made final; rank 0 merges the staged runs at their bit offsets when all totals are in."""
+    _lib.lib()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_piece_worker, args=(r, world, port, total, chunk, pass_chunks, q, piece))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    stream = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    data = _corpus(total)
+    assert stream == zref.compress_chunked(data, zref.DYNAMIC, chunk, fast=True)
+    assert sysz.decompress(stream) == data
+
+
+def test_overlapped_assembly_with_one_rank():
+    """sharding.SingleRank: the same calls with nothing to exchange."""
+    _lib.lib()
+    total, chunk = 70_000, 8192
+    data = _corpus(total)
+    eng = OraclePieceEngine(data, 0, total, chunk, 2)
+    final = torch.full((total * 2 + 4096,), 0xEE, dtype=torch.uint8)
+    n = sharding.compress_sharded_overlapped(eng, sharding.SingleRank, torch, 0, 1, torch.device("cpu"), final=final,
+                                             stages=[None])
+    assert bytes(final[:n].numpy().tobytes()) == zref.compress_chunked(data, zref.DYNAMIC, chunk, fast=True)
+
+
 def _worker(rank, world, port, total, chunk, q, piece=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

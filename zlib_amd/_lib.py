@@ -19,7 +19,7 @@ ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_I
 SYMBOLS = [
     "zg_init", "zg_destroy", "zg_strerror", "zg_last_error", "zg_free", "zg_compress", "zg_compress_bound",
     "zg_compress_device", "zg_compress_multi", "zg_compress_stream", "zg_compress_file", "zg_last_block_offsets", "zg_compress_batch", "zg_compress_batch_bound", "zg_compress_batch_device",
-    "zg_decompress", "zg_decompress_batch", "zg_decompress_batch_device", "zg_decompress_blocks_device", "zg_shard_begin", "zg_shard_finish", "zg_adler32_combine", "zg_adler32",
+    "zg_decompress", "zg_decompress_batch", "zg_decompress_batch_device", "zg_decompress_blocks_device", "zg_shard_begin", "zg_shard_finish", "zg_shard_open", "zg_shard_next", "zg_shard_merge", "zg_shard_seal", "zg_adler32_combine", "zg_adler32",
     "zg_adler32_device", "zg_adler32_device_noalloc", "zg_lz77", "zg_huffman_from_tokens", "zg_profile_enable", "zg_profile_reset",
     "zg_profile_count", "zg_profile_get", "zg_corpus_fill",
 ]
@@ -31,6 +31,10 @@ class Opts(C.Structure):
 
 class ShardInfo(C.Structure):
     _fields_ = [("total_bits", C.c_uint64), ("adler", C.c_uint32), ("n_chunks", C.c_uint32)]
+
+
+class ShardPiece(C.Structure):
+    _fields_ = [("byte_offset", C.c_uint64), ("n_bytes", C.c_uint64), ("bits_so_far", C.c_uint64), ("last", C.c_int)]
 
 
 #: size_t read_fn(void *user, uint8_t *buf, size_t cap) / int write_fn(void *user, const uint8_t *buf, size_t n)
@@ -95,6 +99,10 @@ def _declare(L):
     f("zg_decompress_blocks_device", C.c_int, vp, vp, sz, C.POINTER(C.c_uint64), sz, sz, vp, sz)
     f("zg_shard_begin", C.c_int, vp, vp, sz, sz, C.c_int, C.POINTER(Opts), C.c_int, C.POINTER(ShardInfo))
     f("zg_shard_finish", C.c_int, vp, C.c_uint64, C.c_int, C.c_int, C.c_uint32, vp, sz, C.POINTER(sz))
+    f("zg_shard_open", C.c_int, vp, vp, sz, sz, C.c_int, C.POINTER(Opts), C.c_int, vp, sz)
+    f("zg_shard_next", C.c_int, vp, C.POINTER(ShardPiece), C.POINTER(ShardInfo))
+    f("zg_shard_merge", C.c_int, vp, vp, C.c_uint64, vp, sz, C.c_uint64, C.c_int)
+    f("zg_shard_seal", C.c_int, vp, vp, sz, C.c_uint64, C.c_uint32, C.POINTER(sz))
     f("zg_adler32_combine", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64)
     f("zg_adler32", C.c_int, vp, C.c_char_p, sz, C.POINTER(C.c_uint32))
     f("zg_adler32_device", C.c_int, vp, vp, sz, C.POINTER(C.c_uint32))

@@ -19,7 +19,7 @@ from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple, Union
 
 from . import _lib
-from ._lib import Opts, ShardInfo, ZgError
+from ._lib import Opts, ShardInfo, ShardPiece, ZgError
 
 ZLIB_WINDOW_SIZE = 1 << 15       # src/huffman.rs:47
 ZLIB_MIN_STRING_LENGTH = 3       # src/huffman.rs:48
@@ -306,6 +306,36 @@ def shard_finish(base_bit: int, first_rank: bool, last_rank: bool, adler: int, d
     n_out = C.c_size_t()
     _check(_lib.lib().zg_shard_finish(ctx.handle, base_bit, int(first_rank), int(last_rank), adler, d_out, out_cap,
                                       C.byref(n_out)), ctx)
+    return n_out.value
+
+
+def shard_open(d_in: int, halo: int, n: int, strategy: Strategy, last_rank: bool, d_packed: int, packed_cap: int, *,
+               chunk_bytes: int = 0, batch_bytes: int = 0, ctx: Optional[Context] = None) -> None:
+    """zg_shard_open: starts a rank's run; its blocks are packed into the caller's device buffer pass by pass."""
+    ctx = ctx or default_context()
+    o = _opts(chunk_bytes, batch_bytes)
+    _check(_lib.lib().zg_shard_open(ctx.handle, d_in, halo, n, int(strategy), C.byref(o), int(last_rank), d_packed,
+                                    packed_cap), ctx)
+
+
+def shard_next(*, ctx: Optional[Context] = None):
+    """zg_shard_next: (byte_offset, n_bytes, bits_so_far, last, info or None) of the oldest unreported pass."""
+    ctx = ctx or default_context()
+    piece, info = ShardPiece(), ShardInfo()
+    _check(_lib.lib().zg_shard_next(ctx.handle, C.byref(piece), C.byref(info)), ctx)
+    return piece.byte_offset, piece.n_bytes, piece.bits_so_far, bool(piece.last), (info if piece.last else None)
+
+
+def shard_merge(d_src: int, n_bits: int, d_dst: int, dst_cap: int, base_bit: int, first_run: bool, *,
+                ctx: Optional[Context] = None) -> None:
+    ctx = ctx or default_context()
+    _check(_lib.lib().zg_shard_merge(ctx.handle, d_src, n_bits, d_dst, dst_cap, base_bit, int(first_run)), ctx)
+
+
+def shard_seal(d_dst: int, dst_cap: int, end_bit: int, adler: int, *, ctx: Optional[Context] = None) -> int:
+    ctx = ctx or default_context()
+    n_out = C.c_size_t()
+    _check(_lib.lib().zg_shard_seal(ctx.handle, d_dst, dst_cap, end_bit, adler, C.byref(n_out)), ctx)
     return n_out.value
 
 

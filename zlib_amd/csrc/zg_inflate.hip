@@ -482,74 +482,118 @@ __global__ __launch_bounds__(kInfLanes) void k_inflate_wave(const uint8_t *__res
 // Inflate of ONE stream whose block boundaries are known (the bit offset of every block: what zg_last_block_offsets
 // reports for a stream of this library), all blocks at once.  Block i holds the bytes [i * chunk, (i + 1) * chunk) of
 // the output, so every block can be decoded by a wave of its own -- except that its matches may reach up to 32 KiB
-// back into the output of the block before, which is being decoded at the same time.  Three steps:
-//   k_inflate_blocks   a wave per block decodes into 16-bit units: a byte, or, for a byte copied from before the
-//                      block's start, a marker 0x8000 | offset into the 32 KiB window in front of the block (copies
-//                      of markers copy markers);
+// back into the output of the block before, which is being decoded at the same time.  Four steps:
+//   k_decode_tokens    a wave per block turns the block's bits into tokens (a literal, or length and distance).
+//                      Decoding is serial, so the wave runs it in step: all state is the same in every lane, the
+//                      compiler keeps it in scalar registers and the loop's branches are scalar branches -- a lane
+//                      decoding alone under an execution mask needs several times the instructions.  Input words
+//                      come through scalar loads, one word ahead of their use; literal/length and distance symbols
+//                      are resolved by one look-up each in tables in LDS (codes of up to 10 / 9 bits, with the base
+//                      value and the number of extra bits in the entry; longer codes go on bit by bit).  Token k of a
+//                      group of 64 is written into lane k of a register and the group stored with one instruction.
+//                      No output ring: 7 KiB of LDS per block, a dozen blocks per CU.
+//   k_expand_tokens    a wave per block turns tokens into 16-bit units: a byte, or, for a byte copied from before
+//                      the block's start, a marker 0x8000 | offset into the 32 KiB window in front of the block
+//                      (copies of markers copy markers).  64 tokens at a time: a scan of their lengths gives the
+//                      positions, runs of literals are written by their lanes, every match is copied by the whole
+//                      wave, in stream order, in an LDS ring that holds the last 32 Ki units.
 //   k_resolve_windows  one workgroup goes through the blocks in order and turns the last 32 KiB of every block --
 //                      the window of the next one -- into bytes: 32 KiB of work per block, the only serial part;
 //   k_resolve_all      every unit becomes a byte, markers through the block's window.
-// The decoder itself reads its input from an LDS buffer that the whole wave refills (a lane that fetches its bits
-// from global memory four bytes at a time waits a memory latency every few symbols) and decodes literal/length and
-// distance symbols by one table look-up each (codes of up to 11 / 9 bits; longer ones go on bit by bit).
+// Tokens and units are kept for a pass of blocks at a time (the windows for all).
 // ---------------------------------------------------------------------------------------------------------
 namespace {
-constexpr uint32_t kBlkRing = 65536;            // units in the output ring
-constexpr uint32_t kBlkFlush = 32768 - 512;     // units produced between two flushes
-constexpr uint32_t kBlkIn = 16384;              // bytes of input held in LDS
-constexpr uint32_t kBlkInHalf = kBlkIn / 2;
-constexpr uint32_t kLlBits = 11, kDBits = 9;    // bits the look-up tables resolve at once
+constexpr uint32_t kBlkRing = 32768;            // units in the output ring: exactly the window
+constexpr uint32_t kBlkFlush = 8192;            // units produced between two flushes (at least)
+constexpr uint32_t kLlBits = 10, kDBits = 9;    // bits the look-up tables resolve at once
 constexpr uint32_t kMark = 0x8000u;
+constexpr uint32_t kTokMatch = 0x80000000u;     // a match token: this | (length - 3) << 15 | (distance - 1); else the byte
+// literal/length entry: code length | extra bits << 4 | value << 8 (the byte, or the base length) | kind << 30
+// (0 literal, 1 end of block, 2 length); distance entry: code length | extra bits << 4 | base distance << 8.
+// 0 = the code is longer than the table resolves.  Symbols that must not occur have the base value 0.
+constexpr uint32_t kEntEob = 0x40000000u, kEntLen = 0x80000000u;
 
 struct BlkTabs {
-    uint16_t ll_lut[1u << kLlBits];  // symbol | length << 9; 0 = longer than the table resolves
-    uint16_t d_lut[1u << kDBits];    // symbol | length << 5
+    uint32_t ll_lut[1u << kLlBits];
+    uint32_t d_lut[1u << kDBits];
     uint16_t ll_cnt[16], d_cnt[16];  // canonical counts and symbol order for the codes the tables do not resolve
     uint16_t ll_sym[288], d_sym[32];
     uint16_t offs[16];
     uint8_t lens[320];
 };
 
-// bits out of the LDS input ring, which holds the stream from byte `base` on, kBlkIn bytes at a time
-struct LdsBits {
-    const uint32_t *ring;  // kBlkIn bytes as words
-    uint64_t base;         // absolute byte offset of ring word 0 (the ring is filled from there in order)
-    uint64_t pos;          // bytes taken so far, counted from base (a multiple of four)
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+__device__ __forceinline__ uint32_t ll_entry(uint32_t sym, uint32_t code_len) {
+    if (sym < 256) return code_len | (sym << 8);
+    if (sym == 256) return code_len | kEntEob;
+    const uint32_t li = sym - 257u;
+    if (li > 28) return code_len | kEntLen;  // 286, 287: base 0
+    return code_len | (len_extra(li) << 4) | (len_base(li) << 8) | kEntLen;
+}
+__device__ __forceinline__ uint32_t d_entry(uint32_t sym, uint32_t code_len) {
+    if (sym > 29) return code_len;  // 30, 31: base 0
+    return code_len | (dst_extra(sym) << 4) | (dst_base(sym) << 8);
+}
+
+// Bits of the stream for a decoder that the whole wave runs in step.  `in` is four-byte aligned; bytes from
+// in_bytes on read as zero.
+struct WaveBits {
+    const uint8_t *in;
+    uint64_t in_bytes;
+    uint64_t pos;    // bytes taken into buf so far (a multiple of four); the word at pos is already in nextw
     uint64_t buf;
-    uint32_t cnt;
-    __device__ __forceinline__ void fill() {  // at least 32 bits in buf afterwards
+    uint32_t cnt, nextw;
+    __device__ __forceinline__ uint32_t word(uint64_t p) const {
+        if (p + 4 <= in_bytes) return *reinterpret_cast<const uint32_t *>(in + p);  // a scalar load: not waited for here
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < 4; k++)
+            if (p + k < in_bytes) v |= (uint32_t)in[p + k] << (8 * k);
+        return uni(v);
+    }
+    __device__ __forceinline__ void start(uint64_t bit) {
+        pos = (bit >> 3) & ~(uint64_t)3;
+        const uint32_t skip = (uint32_t)(bit - pos * 8);
+        buf = 0;
+        cnt = 0;
+        nextw = word(pos);
+        fill();
+        drop(skip);
+    }
+    __device__ __forceinline__ void fill() {  // at least 33 bits in buf afterwards
         if (cnt <= 32) {
-            buf |= (uint64_t)ring[(pos >> 2) & (kBlkIn / 4 - 1)] << cnt;
+            buf |= (uint64_t)nextw << cnt;
             cnt += 32;
             pos += 4;
+            nextw = word(pos);
         }
-    }
-    __device__ __forceinline__ uint32_t bits(uint32_t n) {  // n <= 16
-        fill();
-        const uint32_t v = (uint32_t)buf & ((1u << n) - 1u);
-        buf >>= n;
-        cnt -= n;
-        return v;
     }
     __device__ __forceinline__ void drop(uint32_t n) {
         buf >>= n;
         cnt -= n;
     }
-    __device__ __forceinline__ uint64_t taken() const { return base + pos; }                // absolute, bytes
-    __device__ __forceinline__ uint64_t bit_pos() const { return (base + pos) * 8 - cnt; }  // of the next bit
+    __device__ __forceinline__ uint64_t bit_pos() const { return pos * 8 - cnt; }  // of the next bit
 };
 
-// bit-by-bit continuation for codes longer than the table resolves (canonical decoding, as decode_sym)
-__device__ __forceinline__ int slow_sym(LdsBits &b, const uint16_t *cnt, const uint16_t *sym) {
-    b.fill();
+// code counts per length 1..15 in registers, the same in every lane
+struct WaveCounts {
+    uint32_t w[8];
+    __device__ __forceinline__ void load(const uint16_t *cnt) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = uni((uint32_t)cnt[2 * i] | ((uint32_t)cnt[2 * i + 1] << 16));
+    }
+};
+// bit-by-bit continuation for codes longer than the table resolves (canonical decoding, as decode_sym); the code's
+// bits are dropped.  -1: the bits match no code.
+__device__ __forceinline__ int wave_slow_sym(WaveBits &b, const WaveCounts &c, const uint16_t *sym) {
     const uint32_t v = (uint32_t)b.buf;
     int code = 0, first = 0, index = 0;
     for (int l = 1; l < 16; l++) {
         code |= (int)((v >> (l - 1)) & 1u);
-        const int n = (int)cnt[l];
+        const int n = (int)((c.w[l >> 1] >> ((l & 1) * 16)) & 0xFFFFu);
         if (code - n < first) {
             b.drop((uint32_t)l);
-            return (int)sym[index + (code - first)];
+            return (int)uni(sym[index + (code - first)]);
         }
         index += n;
         first += n;
@@ -561,72 +605,42 @@ __device__ __forceinline__ int slow_sym(LdsBits &b, const uint16_t *cnt, const u
 __device__ __forceinline__ uint32_t rev_bits(uint32_t v, uint32_t n) { return __brev(v) >> (32u - n); }
 }  // namespace
 
-__global__ __launch_bounds__(kInfLanes) void k_inflate_blocks(const uint8_t *__restrict__ in, uint64_t in_bytes,
-                                                               const uint64_t *__restrict__ bit_off, uint32_t n_blocks,
-                                                               uint64_t chunk, uint64_t out_total,
-                                                               uint16_t *__restrict__ units,
-                                                               uint32_t *__restrict__ status) {
-    __shared__ uint16_t s_ring[kBlkRing];
-    __shared__ __attribute__((aligned(16))) uint32_t s_in[kBlkIn / 4];
+// tok: tok_stride entries per block (at least chunk + 64, a multiple of 64); ntok / status: one entry per block of the
+// pass (status has two more entries behind the stream's last block: the bit at which that block ended).  `in` is
+// four-byte aligned and the bit offsets count from it.
+__global__ __launch_bounds__(kInfLanes) void k_decode_tokens(const uint8_t *__restrict__ in, uint64_t in_bytes,
+                                                              const uint64_t *__restrict__ bit_off, uint64_t bit_shift,
+                                                              uint32_t b0, uint32_t n_blocks, uint64_t chunk,
+                                                              uint64_t out_total, uint32_t *__restrict__ tok,
+                                                              uint64_t tok_stride, uint32_t *__restrict__ ntok,
+                                                              uint32_t *__restrict__ status) {
     __shared__ BlkTabs s_t;
-    __shared__ uint64_t s_n;       // units produced so far
-    __shared__ uint64_t s_need;    // the decoder has taken every input byte below this (absolute)
-    __shared__ uint32_t s_state;   // 0 running, 1 end of block, 2+ failed with InflateStatus (state - 2)
-    const uint32_t blk = blockIdx.x, lane = threadIdx.x;
+    __shared__ uint64_t s_bit;     // where the header ended
+    __shared__ uint32_t s_state;   // 0 running, 2+ failed with InflateStatus (state - 2)
+    const uint32_t blk = b0 + blockIdx.x, lane = threadIdx.x;
     const uint64_t out0 = (uint64_t)blk * chunk;
     const uint64_t want = out0 + chunk <= out_total ? chunk : out_total - out0;  // bytes this block must give
-    const uint64_t bit0 = bit_off[blk];
-    const uint64_t in0 = (bit0 >> 3) & ~(uint64_t)3;  // first input byte taken (four-byte steps from here on)
-    uint16_t *const o = units + out0;
+    const uint64_t bit0 = bit_off[blk] + bit_shift;
+    uint32_t *const tk = tok + (uint64_t)blockIdx.x * tok_stride;
 
-    // the window in front of the block: markers
-    for (uint32_t j = lane; j < 32768; j += kInfLanes) s_ring[kBlkRing - 32768 + j] = (uint16_t)(kMark | j);
-    // input: bytes [in0 + k * kBlkInHalf, ...) live in half (k & 1) of the ring; `loaded` = one past the last byte held
-    uint64_t loaded = in0;
-    auto refill = [&](uint64_t upto) {  // all lanes: load half-rings until `upto` bytes are there
-        while (loaded < upto) {
-            const uint32_t half = (uint32_t)((loaded - in0) / kBlkInHalf) & 1u;
-            for (uint32_t w = lane; w < kBlkInHalf / 4; w += kInfLanes) {
-                const uint64_t at = loaded + (uint64_t)w * 4;
-                uint32_t v = 0;
-                if (at + 4 <= in_bytes) {
-                    __builtin_memcpy(&v, in + at, 4);
-                } else {
-                    for (uint32_t k = 0; k < 4; k++)
-                        if (at + k < in_bytes) v |= (uint32_t)in[at + k] << (8 * k);
-                }
-                s_in[half * (kBlkInHalf / 4) + w] = v;
-            }
-            loaded += kBlkInHalf;
-        }
-    };
-    refill(in0 + kBlkIn);
+    // ---- block header (lane 0; a few hundred bits) ----
     if (lane == 0) {
-        s_n = 0;
-        s_state = 0;
-        s_need = in0;
-    }
-    __syncthreads();
-
-    LdsBits b;
-    b.ring = s_in;
-    b.base = in0;
-    b.pos = 0;
-    b.buf = 0;
-    b.cnt = 0;
-    uint32_t st = INF_OK;
-    bool fixed = false;
-    // ---- block header (lane 0) ----
-    if (lane == 0) {
-        b.fill();
-        b.drop((uint32_t)(bit0 - in0 * 8));  // at most 31 bits
+        uint32_t st = INF_OK;
+        BitSrc b;
+        b.in = in;
+        b.pos = bit0 >> 3;
+        b.end = in_bytes;
+        b.buf = 0;
+        b.cnt = 0;
+        b.pad = 0;
+        b.over = false;
+        (void)b.bits((uint32_t)(bit0 & 7));
         const uint32_t bfinal = b.bits(1);
         const uint32_t type = b.bits(2);
         if ((bfinal != 0) != (blk + 1 == n_blocks)) st = INF_BAD_BLOCK;  // the last block, and only it, is final
         if (type == 0 || type == 3) {
             st = INF_BAD_BLOCK;  // stored blocks are not cut at chunks: such a stream goes through zg_decompress
         } else if (type == 1) {
-            fixed = true;
             for (uint32_t i = 0; i < 288; i++) s_t.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
             for (uint32_t i = 0; i < 30; i++) s_t.lens[288 + i] = 5;
             s_t.offs[0] = 288;
@@ -639,9 +653,11 @@ __global__ __launch_bounds__(kInfLanes) void k_inflate_blocks(const uint8_t *__r
             for (uint32_t i = 0; i < 19; i++) cl[i] = 0;
             for (uint32_t i = 0; i < ncode && st == INF_OK; i++) cl[order[i]] = (uint8_t)b.bits(3);
             if (st == INF_OK && !make_code(s_t.d_cnt, s_t.d_sym, s_t.offs, cl, 19)) st = INF_BAD_CODES;
+            Counts cc;
+            cc.load(s_t.d_cnt);
             uint32_t i = 0;
             while (st == INF_OK && i < nlen + ndist) {
-                const int sy = slow_sym(b, s_t.d_cnt, s_t.d_sym);
+                const int sy = decode_sym(b, cc, s_t.d_sym);
                 if (sy < 0) {
                     st = INF_BAD_CODES;
                 } else if (sy < 16) {
@@ -683,12 +699,16 @@ __global__ __launch_bounds__(kInfLanes) void k_inflate_blocks(const uint8_t *__r
                 !make_code(s_t.d_cnt, s_t.d_sym, s_t.offs, s_t.lens + 288, ndist))
                 st = INF_BAD_CODES;
         }
+        if (st == INF_OK && (b.over || b.pad)) st = INF_TRUNCATED;
+        s_bit = b.pos * 8 - b.cnt;
         s_state = st == INF_OK ? 0u : 2u + st;
     }
-    (void)fixed;
     __syncthreads();
     if (s_state != 0) {
-        if (lane == 0) status[blk] = s_state - 2u;
+        if (lane == 0) {
+            status[blk] = s_state - 2u;
+            ntok[blockIdx.x] = 0;
+        }
         return;
     }
     // ---- look-up tables (all lanes): canonical codes in symbol order, stored bit-reversed (the stream carries a
@@ -717,9 +737,9 @@ __global__ __launch_bounds__(kInfLanes) void k_inflate_blocks(const uint8_t *__r
         for (uint32_t l = 1; l <= kLlBits; l++) {
             const uint32_t n = s_t.ll_cnt[l];
             for (uint32_t r = lane; r < n; r += kInfLanes) {
-                const uint32_t sym = s_t.ll_sym[base + r];
+                const uint32_t e = ll_entry(s_t.ll_sym[base + r], l);
                 const uint32_t rc = rev_bits(first_ll[l] + r, l);
-                for (uint32_t k = rc; k < (1u << kLlBits); k += 1u << l) s_t.ll_lut[k] = (uint16_t)(sym | (l << 9));
+                for (uint32_t k = rc; k < (1u << kLlBits); k += 1u << l) s_t.ll_lut[k] = e;
             }
             base += n;
         }
@@ -727,114 +747,187 @@ __global__ __launch_bounds__(kInfLanes) void k_inflate_blocks(const uint8_t *__r
         for (uint32_t l = 1; l <= kDBits; l++) {
             const uint32_t n = s_t.d_cnt[l];
             for (uint32_t r = lane; r < n; r += kInfLanes) {
-                const uint32_t sym = s_t.d_sym[base + r];
+                const uint32_t e = d_entry(s_t.d_sym[base + r], l);
                 const uint32_t rc = rev_bits(first_d[l] + r, l);
-                for (uint32_t k = rc; k < (1u << kDBits); k += 1u << l) s_t.d_lut[k] = (uint16_t)(sym | (l << 5));
+                for (uint32_t k = rc; k < (1u << kDBits); k += 1u << l) s_t.d_lut[k] = e;
             }
             base += n;
         }
     }
     __syncthreads();
 
-    // ---- symbols (lane 0), flushes and refills (all lanes) ----
-    uint64_t n = 0, flushed = 0;
+    // ---- symbols: the whole wave in step ----
+    WaveCounts llc, dc;
+    llc.load(s_t.ll_cnt);
+    dc.load(s_t.d_cnt);
+    WaveBits b;
+    b.in = in;
+    b.in_bytes = in_bytes;
+    b.start((uint64_t)uni((uint32_t)s_bit) | ((uint64_t)uni((uint32_t)(s_bit >> 32)) << 32));
+    uint32_t st = INF_OK, nt = 0, tokv = 0;
+    uint64_t n = 0;
     for (;;) {
-        if (lane == 0) {
-            while (st == INF_OK) {
-                if (n - flushed >= kBlkFlush || b.taken() + 64 > loaded) break;  // room for the longest match / bits at hand
-                b.fill();
-                uint32_t e = s_t.ll_lut[(uint32_t)b.buf & ((1u << kLlBits) - 1u)];
-                int sy;
-                if (e) {
-                    b.drop(e >> 9);
-                    sy = (int)(e & 0x1FFu);
-                } else {
-                    sy = slow_sym(b, s_t.ll_cnt, s_t.ll_sym);
-                }
-                if (sy < 0) {
+        b.fill();
+        uint32_t e = uni(s_t.ll_lut[(uint32_t)b.buf & ((1u << kLlBits) - 1u)]);
+        if (e != 0) {
+            b.drop(e & 15u);
+        } else {
+            const int sy = wave_slow_sym(b, llc, s_t.ll_sym);
+            if (sy < 0) {
+                st = INF_BAD_SYMBOL;
+                break;
+            }
+            e = ll_entry((uint32_t)sy, 0);
+        }
+        uint32_t t;
+        if ((e >> 30) == 0) {
+            t = (e >> 8) & 0xFFu;
+            n += 1;
+        } else if (e & kEntEob) {
+            break;
+        } else {
+            const uint32_t xb = (e >> 4) & 15u;
+            const uint32_t len = ((e >> 8) & 0x1FFu) + ((uint32_t)b.buf & ((1u << xb) - 1u));
+            if (((e >> 8) & 0x1FFu) == 0) {
+                st = INF_BAD_SYMBOL;
+                break;
+            }
+            b.drop(xb);
+            b.fill();
+            uint32_t f = uni(s_t.d_lut[(uint32_t)b.buf & ((1u << kDBits) - 1u)]);
+            if (f != 0) {
+                b.drop(f & 15u);
+            } else {
+                const int ds = wave_slow_sym(b, dc, s_t.d_sym);
+                if (ds < 0) {
                     st = INF_BAD_SYMBOL;
-                } else if (sy < 256) {
-                    s_ring[n & (kBlkRing - 1)] = (uint16_t)sy;
-                    n++;
-                } else if (sy == 256) {
-                    st = 0x100u;  // end of block
-                } else {
-                    const uint32_t li = (uint32_t)sy - 257u;
-                    if (li > 28) {
-                        st = INF_BAD_SYMBOL;
-                        break;
-                    }
-                    const uint32_t len = len_base(li) + b.bits(len_extra(li));
-                    b.fill();
-                    e = s_t.d_lut[(uint32_t)b.buf & ((1u << kDBits) - 1u)];
-                    int ds;
-                    if (e) {
-                        b.drop(e >> 5);
-                        ds = (int)(e & 0x1Fu);
-                    } else {
-                        ds = slow_sym(b, s_t.d_cnt, s_t.d_sym);
-                    }
-                    if (ds < 0 || ds > 29) {
-                        st = INF_BAD_SYMBOL;
-                        break;
-                    }
-                    const uint32_t dist = dst_base((uint32_t)ds) + b.bits(dst_extra((uint32_t)ds));
-                    // before the start of the stream, or more than a window back
-                    if (dist > n + (blk ? 32768u : 0u) || (blk && dist > n && out0 < dist - n)) {
-                        st = INF_BAD_DISTANCE;
-                        break;
-                    }
-                    for (uint32_t k = 0; k < len; k++) {
-                        s_ring[n & (kBlkRing - 1)] = s_ring[(n - dist) & (kBlkRing - 1)];
-                        n++;
-                    }
+                    break;
                 }
-                if (n > want) st = INF_OVERFLOW;  // more than the block's share of the output
+                f = d_entry((uint32_t)ds, 0);
             }
-            s_n = n;
-            s_need = b.taken();
-            s_state = st == INF_OK ? 0u : (st == 0x100u ? 1u : 2u + st);
-        }
-        __syncthreads();
-        n = s_n;
-        const uint32_t state = s_state;
-        const uint64_t upto = n < want ? n : want;
-        for (uint64_t j = flushed + lane; j < upto; j += kInfLanes) o[j] = s_ring[j & (kBlkRing - 1)];
-        flushed = n;
-        if (state != 0) {
-            if (lane == 0) {
-                uint32_t fin = state == 1 ? INF_OK : state - 2u;
-                if (fin == INF_OK && n != want) fin = INF_TRUNCATED;  // the block ended short of its share
-                // where the block ended: the next block must begin there (the last one: the trailer, after padding)
-                if (fin == INF_OK && blk + 1 < n_blocks && b.bit_pos() != bit_off[blk + 1]) fin = INF_BAD_BLOCK;
-                if (blk + 1 == n_blocks) {  // behind the statuses: the bit at which the last block ended
-                    const uint64_t e = b.bit_pos();
-                    status[n_blocks] = (uint32_t)e;
-                    status[n_blocks + 1] = (uint32_t)(e >> 32);
-                }
-                status[blk] = fin;
+            const uint32_t yb = (f >> 4) & 15u;
+            const uint32_t dist = (f >> 8) + ((uint32_t)b.buf & ((1u << yb) - 1u));
+            if ((f >> 8) == 0) {
+                st = INF_BAD_SYMBOL;
+                break;
             }
-            return;
+            b.drop(yb);
+            // before the start of the stream, or more than a window back
+            if (dist > n + (blk ? 32768u : 0u) || (blk && dist > n && out0 < dist - n)) {
+                st = INF_BAD_DISTANCE;
+                break;
+            }
+            t = kTokMatch | ((len - 3u) << 15) | (dist - 1u);
+            n += len;
         }
-        refill(s_need + kBlkIn - kBlkInHalf);  // every half below the reader's position is free
-        __syncthreads();
+        if (n > want) {  // more than the block's share of the output
+            st = INF_OVERFLOW;
+            break;
+        }
+        tokv = lane == (nt & 63u) ? t : tokv;
+        nt++;
+        if ((nt & 63u) == 0) tk[nt - 64u + lane] = tokv;
+    }
+    if (nt & 63u) tk[(nt & ~63u) + lane] = tokv;  // the lanes behind the last token hold old ones: never read
+    if (st == INF_OK && n != want) st = INF_TRUNCATED;  // the block ended short of its share
+    // where the block ended: the next block must begin there (the last one: the trailer, after padding)
+    if (st == INF_OK && blk + 1 < n_blocks && b.bit_pos() != bit_off[blk + 1] + bit_shift) st = INF_BAD_BLOCK;
+    if (lane == 0) {
+        if (blk + 1 == n_blocks) {  // behind the statuses: the bit at which the last block ended
+            const uint64_t e = b.bit_pos() - bit_shift;
+            status[n_blocks] = (uint32_t)e;
+            status[n_blocks + 1] = (uint32_t)(e >> 32);
+        }
+        status[blk] = st;
+        ntok[blockIdx.x] = st == INF_OK ? nt : 0u;
     }
 }
 
-// the window of block i + 1 = the last 32 KiB of block i, as bytes.  One workgroup, blocks in order; the window of
-// the block in hand stays in LDS.  win holds 32 KiB per block (block 0 has none).
-__global__ __launch_bounds__(1024) void k_resolve_windows(const uint16_t *__restrict__ units, uint32_t n_blocks,
-                                                           uint64_t chunk, uint8_t *__restrict__ win) {
+// units of block b0 + blockIdx.x from its tokens; `units` holds the blocks of the pass, chunk entries each
+__global__ __launch_bounds__(kInfLanes) void k_expand_tokens(const uint32_t *__restrict__ tok, uint64_t tok_stride,
+                                                              const uint32_t *__restrict__ ntok, uint32_t b0,
+                                                              uint64_t chunk, uint16_t *__restrict__ units) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_ring[kBlkRing];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t nt = ntok[blockIdx.x];
+    if (nt == 0) return;  // an empty block, or one that did not decode
+    const uint32_t *const tk = tok + (uint64_t)blockIdx.x * tok_stride;
+    uint16_t *const o = units + (uint64_t)blockIdx.x * chunk;
+    // the window in front of the block: markers (unit -32768 + j lives in slot j).  The first block of the stream has
+    // no window; its decoder has refused every distance that reaches in front of it.
+    for (uint32_t j = lane; j < 32768; j += kInfLanes) s_ring[j] = (uint16_t)(kMark | j);
+    __syncthreads();
+    uint32_t pos = 0, flushed = 0;  // units so far; flushed is a multiple of 8
+    uint32_t ahead = lane < nt ? tk[lane] : 0u;
+    for (uint32_t t0 = 0; t0 < nt; t0 += kInfLanes) {
+        const uint32_t t = ahead;
+        if (t0 + kInfLanes < nt) ahead = t0 + kInfLanes + lane < nt ? tk[t0 + kInfLanes + lane] : 0u;  // the next group
+        const bool valid = t0 + lane < nt;
+        const bool is_m = valid && (t & kTokMatch);
+        const uint32_t len = !valid ? 0u : is_m ? ((t >> 15) & 0xFFu) + 3u : 1u;
+        uint32_t incl = len;
+        for (uint32_t off = 1; off < kInfLanes; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        const uint32_t at = pos + incl - len;  // where this lane's token begins
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint64_t mm = __ballot(is_m);
+        int prev = -1;
+        while (mm) {
+            const int m = __builtin_ctzll(mm);
+            mm &= mm - 1;
+            if (m > prev + 1 && (int)lane > prev && (int)lane < m) s_ring[at & (kBlkRing - 1)] = (uint16_t)(t & 0xFFu);
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)at, m);
+            const uint32_t tm = (uint32_t)__builtin_amdgcn_readlane((int)t, m);
+            const uint32_t dist = (tm & 0x7FFFu) + 1u, ml = ((tm >> 15) & 0xFFu) + 3u;
+            // the match's units in parallel (a source that reaches into the match itself repeats with period `dist`)
+            for (uint32_t k = lane; k < ml; k += kInfLanes) {
+                uint32_t kk = k;
+                if (kk >= dist) kk %= dist;
+                const uint16_t v = s_ring[(a - dist + kk) & (kBlkRing - 1)];
+                s_ring[(a + k) & (kBlkRing - 1)] = v;
+            }
+            prev = m;
+        }
+        if (valid && !is_m && (int)lane > prev) s_ring[at & (kBlkRing - 1)] = (uint16_t)(t & 0xFFu);
+        pos += total;
+        const bool last = t0 + kInfLanes >= nt;
+        if (pos - flushed >= kBlkFlush || last) {
+            __syncthreads();
+            const uint32_t whole = pos & ~7u;  // eight units to a lane and store; what is left goes with the next flush
+            for (uint32_t j = flushed + lane * 8; j < whole; j += kInfLanes * 8)
+                *reinterpret_cast<uint4 *>(o + j) = *reinterpret_cast<const uint4 *>(&s_ring[j & (kBlkRing - 1)]);
+            flushed = whole;
+            if (last)  // ... or, at the end, unit by unit
+                for (uint32_t j = whole + lane; j < pos; j += kInfLanes) o[j] = s_ring[j & (kBlkRing - 1)];
+            __syncthreads();
+        }
+    }
+}
+
+// the window of block i + 1 = the last 32 KiB of block i, as bytes, for the blocks [b0, b1) of a pass.  One
+// workgroup, blocks in order; the window of the block in hand stays in LDS (the first one's comes from the pass
+// before).  win holds 32 KiB per block of the stream (block 0 has none); units holds the blocks of the pass.
+__global__ __launch_bounds__(1024) void k_resolve_windows(const uint16_t *__restrict__ units, uint32_t b0, uint32_t b1,
+                                                           uint32_t n_blocks, uint64_t chunk, uint8_t *__restrict__ win) {
     __shared__ uint8_t s_win[2][32768];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = 0; i + 1 < n_blocks; i++) {
-        const uint16_t *tail = units + (uint64_t)(i + 1) * chunk - 32768;  // chunk >= 32768
+    if (b0 > 0)
+        for (uint32_t j = tid; j < 32768; j += 1024) s_win[b0 & 1][j] = win[(uint64_t)b0 * 32768 + j];
+    __syncthreads();
+    for (uint32_t i = b0; i < b1 && i + 1 < n_blocks; i++) {
+        const uint16_t *tail = units + (uint64_t)(i - b0 + 1) * chunk - 32768;  // chunk >= 32768
         const uint8_t *prev = s_win[i & 1];
         uint8_t *cur = s_win[(i + 1) & 1];
         uint8_t *w = win + (uint64_t)(i + 1) * 32768;
-        for (uint32_t j = tid; j < 32768; j += 1024) {
-            const uint32_t u = tail[j];
-            const uint8_t v = (u & kMark) ? prev[u & 0x7FFFu] : (uint8_t)u;  // block 0 holds no markers
+        uint32_t u[32];
+#pragma unroll
+        for (uint32_t k = 0; k < 32; k++) u[k] = tail[tid + k * 1024];  // all loads in flight together
+#pragma unroll
+        for (uint32_t k = 0; k < 32; k++) {
+            const uint32_t j = tid + k * 1024;
+            const uint8_t v = (u[k] & kMark) ? prev[u[k] & 0x7FFFu] : (uint8_t)u[k];  // block 0 holds no markers
             cur[j] = v;
             w[j] = v;
         }
@@ -842,12 +935,15 @@ __global__ __launch_bounds__(1024) void k_resolve_windows(const uint16_t *__rest
     }
 }
 
-__global__ __launch_bounds__(256) void k_resolve_all(const uint16_t *__restrict__ units, uint64_t n, uint64_t chunk,
-                                                      const uint8_t *__restrict__ win, uint8_t *__restrict__ out) {
-    const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    if (p0 >= n) return;
-    if (p0 + 8 <= n && (p0 % chunk) + 8 <= chunk) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(units + p0);  // p0 is a multiple of 8: 16-byte aligned
+// bytes [first, first + n) of the output from the pass's units (first = the pass's first block * chunk)
+__global__ __launch_bounds__(256) void k_resolve_all(const uint16_t *__restrict__ units, uint64_t first, uint64_t n,
+                                                      uint64_t chunk, const uint8_t *__restrict__ win,
+                                                      uint8_t *__restrict__ out) {
+    const uint64_t q0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;  // inside the pass
+    if (q0 >= n) return;
+    const uint64_t p0 = first + q0;
+    if (q0 + 8 <= n && (p0 % chunk) + 8 <= chunk) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(units + q0);  // q0 is a multiple of 8: 16-byte aligned
         const uint32_t u[8] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16, q.z & 0xFFFFu, q.z >> 16, q.w & 0xFFFFu, q.w >> 16};
         const uint8_t *w = win + (p0 / chunk) * 32768;
         uint64_t r = 0;
@@ -858,24 +954,37 @@ __global__ __launch_bounds__(256) void k_resolve_all(const uint16_t *__restrict_
         }
         *reinterpret_cast<uint64_t *>(out + p0) = r;
     } else {
-        for (uint64_t p = p0; p < p0 + 8 && p < n; p++) {
-            const uint32_t u = units[p];
-            out[p] = (u & kMark) ? win[(p / chunk) * 32768 + (u & 0x7FFFu)] : (uint8_t)u;
+        for (uint64_t q = q0; q < q0 + 8 && q < n; q++) {
+            const uint32_t u = units[q];
+            out[first + q] = (u & kMark) ? win[((first + q) / chunk) * 32768 + (u & 0x7FFFu)] : (uint8_t)u;
         }
     }
 }
 
+// Blocks are decoded `pass_blocks` at a time: tok holds pass_blocks * inflate_tok_stride(chunk) entries, units
+// pass_blocks * chunk, ntok pass_blocks; win 32 KiB and status one entry per block of the stream (+ 2).
+uint64_t inflate_tok_stride(uint64_t chunk) { return (chunk + 64 + 63) & ~(uint64_t)63; }
+
 hipError_t launch_inflate_blocks(const uint8_t *in, uint64_t in_bytes, const uint64_t *bit_off, uint32_t n_blocks,
-                                 uint64_t chunk, uint64_t out_total, uint16_t *units, uint8_t *win, uint8_t *out,
-                                 uint32_t *status, hipStream_t s) {
-    if (!n_blocks) return hipSuccess;
-    hipLaunchKernelGGL(k_inflate_blocks, dim3(n_blocks), dim3(kInfLanes), 0, s, in, in_bytes, bit_off, n_blocks, chunk,
-                       out_total, units, status);
-    if (n_blocks > 1)
-        hipLaunchKernelGGL(k_resolve_windows, dim3(1), dim3(1024), 0, s, units, n_blocks, chunk, win);
-    if (out_total)
-        hipLaunchKernelGGL(k_resolve_all, dim3((uint32_t)((out_total + 2047) / 2048)), dim3(256), 0, s, units, out_total,
-                           chunk, win, out);
+                                 uint64_t chunk, uint64_t out_total, uint32_t pass_blocks, uint32_t *tok, uint32_t *ntok,
+                                 uint16_t *units, uint8_t *win, uint8_t *out, uint32_t *status, hipStream_t s) {
+    if (!n_blocks || !pass_blocks) return hipSuccess;
+    // the decoder loads words: it starts from the aligned address below `in` and counts its bits from there
+    const uint64_t mis = reinterpret_cast<uintptr_t>(in) & 3u;
+    const uint64_t stride = inflate_tok_stride(chunk);
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += pass_blocks) {
+        const uint32_t b1 = n_blocks - b0 < pass_blocks ? n_blocks : b0 + pass_blocks;
+        const uint64_t first = (uint64_t)b0 * chunk;
+        const uint64_t n = ((uint64_t)b1 * chunk < out_total ? (uint64_t)b1 * chunk : out_total) - first;
+        hipLaunchKernelGGL(k_decode_tokens, dim3(b1 - b0), dim3(kInfLanes), 0, s, in - mis, in_bytes + mis, bit_off, mis * 8,
+                           b0, n_blocks, chunk, out_total, tok, stride, ntok, status);
+        hipLaunchKernelGGL(k_expand_tokens, dim3(b1 - b0), dim3(kInfLanes), 0, s, tok, stride, ntok, b0, chunk, units);
+        if (n_blocks > 1)
+            hipLaunchKernelGGL(k_resolve_windows, dim3(1), dim3(1024), 0, s, units, b0, b1, n_blocks, chunk, win);
+        if (n)
+            hipLaunchKernelGGL(k_resolve_all, dim3((uint32_t)((n + 2047) / 2048)), dim3(256), 0, s, units, first, n, chunk,
+                               win, out);
+    }
     return hipGetLastError();
 }
 

@@ -199,9 +199,10 @@ hipError_t launch_inflate(const uint8_t *in, const uint64_t *in_off, uint32_t n_
 // One stream with known block boundaries, all blocks at once: bit_off[i] = bit offset of block i in `in`, block i
 // inflates to output bytes [i * chunk, (i + 1) * chunk) (the last to what is left of out_total); chunk >= 32768.
 // units: 2 bytes per output byte of scratch, win: 32 KiB per block; status[i] = InflateStatus of block i.
+uint64_t inflate_tok_stride(uint64_t chunk);
 hipError_t launch_inflate_blocks(const uint8_t *in, uint64_t in_bytes, const uint64_t *bit_off, uint32_t n_blocks,
-                                 uint64_t chunk, uint64_t out_total, uint16_t *units, uint8_t *win, uint8_t *out,
-                                 uint32_t *status, hipStream_t s);
+                                 uint64_t chunk, uint64_t out_total, uint32_t pass_blocks, uint32_t *tok, uint32_t *ntok,
+                                 uint16_t *units, uint8_t *win, uint8_t *out, uint32_t *status, hipStream_t s);
 hipError_t launch_trailer(uint8_t *out, const uint64_t *total_bits, const uint32_t *adler_state,
                           uint32_t adler_override, int use_override, int write_header, int write_adler,
                           uint64_t *out_bytes, hipStream_t s);

@@ -14,6 +14,19 @@ only exchange is:
 The compute is behind an `engine` object with two calls, so that the same
 assembly logic runs over RCCL with the HIP engine (HipEngine) and over gloo on
 the CPU with a stand-in engine in the tests.
+
+compress_sharded_overlapped is the same job with the payload exchange running
+beside the kernels: every rank compresses its run pass by pass (one pass = the
+chunks that fit the scratch buffers), and the bytes a pass has made final
+travel to rank 0 while the GPU works on the next pass.  Per pass there is one
+all_gather of five integers per rank (the piece's byte count, the bits so far,
+the Adler-32 once known, a flag, the rank's input bytes) -- it tells rank 0
+what to receive -- and one point-to-point send per rank.  Rank 0 keeps every
+rank's bytes in a staging buffer of that rank's (they start at bit 0 there: where
+a run lands in the stream is only known when all runs before it are complete)
+and, once all totals are in, moves each run to its bit offset with one pass of
+a device kernel over the compressed bytes.  What is left on the critical path
+after the last pass's kernels: that pass's piece on the wire, and the merge.
 """
 from __future__ import annotations
 
@@ -130,4 +143,116 @@ def compress_sharded(engine, dist, torch, rank: int, world: int, device, final=N
             ops.append(dist.P2POp(dist.isend, src[lo:min(nb, lo + P2P_PIECE)], 0))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+    return total_bytes
+
+
+class HipPieceEngine:
+    """zg_shard_open / zg_shard_next on this rank's GPU, zg_shard_merge / zg_shard_seal on rank 0's."""
+
+    def __init__(self, ctx, d_in_ptr: int, halo: int, n: int, strategy, chunk_bytes: int, batch_bytes: int, packed):
+        self.ctx, self.d_in, self.halo, self.n = ctx, d_in_ptr, halo, n
+        self.strategy, self.chunk_bytes, self.batch_bytes, self.packed = strategy, chunk_bytes, batch_bytes, packed
+
+    def open(self, last_rank: bool) -> None:
+        api.shard_open(self.d_in, self.halo, self.n, self.strategy, last_rank, self.packed.data_ptr(),
+                       self.packed.numel(), chunk_bytes=self.chunk_bytes, batch_bytes=self.batch_bytes, ctx=self.ctx)
+
+    def next(self):
+        off, nb, bits, last, info = api.shard_next(ctx=self.ctx)
+        return off, nb, bits, last, (info.adler if last else None)
+
+    def merge(self, src, n_bits: int, final, base_bit: int, first_run: bool) -> None:
+        api.shard_merge(src.data_ptr(), n_bits, final.data_ptr(), final.numel(), base_bit, first_run, ctx=self.ctx)
+
+    def seal(self, final, end_bit: int, adler: int) -> int:
+        return api.shard_seal(final.data_ptr(), final.numel(), end_bit, adler, ctx=self.ctx)
+
+
+def stage_bytes(n: int, bound) -> int:
+    """Bytes rank 0 needs to stage a run of n input bytes (`bound` = compress_bound for the run's options)."""
+    return bound(n) + 8
+
+
+class SingleRank:
+    """Stands in for torch.distributed when one rank makes the whole stream: the gather is a copy, nothing is sent.
+    It lets a one-GPU run go through the same shard calls as a multi-GPU one (bench.py measures what they cost)."""
+
+    @staticmethod
+    def get_backend():
+        return "single"
+
+    @staticmethod
+    def all_gather_into_tensor(out, inp):
+        out.copy_(inp)
+
+
+def compress_sharded_overlapped(engine, dist, torch, rank: int, world: int, device, final=None, stages=None,
+                                scratch=None):
+    """One sharded compress with the exchange beside the kernels.  Returns the stream length in bytes; on rank 0
+    `final[:length]` holds the stream.  `engine.packed` is the rank's own packed buffer; `stages[r]` (rank 0 only,
+    r >= 1) a 4-byte aligned uint8 tensor of at least stage_bytes(rank r's input bytes) on `device`."""
+    first, last_rank = rank == 0, rank == world - 1
+    if scratch is None:
+        scratch = {}
+    local = scratch.setdefault("piece", torch.zeros(5, dtype=torch.int64, device=device))
+    gathered = scratch.setdefault("pieces", torch.zeros(5 * world, dtype=torch.int64, device=device))
+    packed = engine.packed
+    staged = packed.is_cuda and dist.get_backend() not in ("nccl", "single")  # see compress_sharded
+    engine.open(last_rank)
+    done, got, totals = [False] * world, [0] * world, [None] * world
+    mine = None  # (bits, adler) once this rank's last piece is out
+    while not all(done):
+        if mine is None:
+            off, nb, bits, last, ad = engine.next()  # queues the next pass's kernels, then waits for the oldest pass
+            row = [nb, bits, ad if last else 0, 1 if last else 0, engine.n]
+            if last:
+                mine = (bits, ad)
+        else:
+            off, nb, row = 0, 0, [0, mine[0], mine[1], 1, engine.n]
+        local.copy_(torch.tensor(row, dtype=torch.int64))
+        try:
+            dist.all_gather_into_tensor(gathered, local)
+        except (RuntimeError, NotImplementedError):
+            parts = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(parts, local)
+            gathered.copy_(torch.cat(parts))
+        rows = gathered.view(world, 5).tolist()
+        ops, landed = [], []
+        if first:
+            for r in range(1, world):
+                nbr = int(rows[r][0])
+                if stages[r].numel() < got[r] + nbr + 8:
+                    raise ValueError(f"staging buffer of rank {r} is too small")
+                for lo in range(0, nbr, P2P_PIECE):
+                    view = stages[r].narrow(0, got[r] + lo, min(nbr - lo, P2P_PIECE))
+                    if staged:
+                        host = torch.empty(view.numel(), dtype=torch.uint8)
+                        landed.append((view, host))
+                        view = host
+                    ops.append(dist.P2POp(dist.irecv, view, r))
+                got[r] += nbr
+        elif nb:
+            src = packed.narrow(0, off, nb)
+            if staged:
+                src = src.cpu()
+            for lo in range(0, nb, P2P_PIECE):
+                ops.append(dist.P2POp(dist.isend, src.narrow(0, lo, min(nb - lo, P2P_PIECE)), 0))
+        if ops:  # the GPU has the next pass queued: it computes while these bytes travel
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for view, host in landed:
+            view.copy_(host)
+        for r in range(world):
+            if rows[r][3]:
+                done[r], totals[r] = True, (int(rows[r][1]), int(rows[r][2]), int(rows[r][4]))
+    bases, end_bit, adler = stream_layout(totals)
+    total_bytes = (end_bit + 7) // 8 + 4
+    if first:
+        if packed.is_cuda:
+            torch.cuda.current_stream(device).synchronize()  # the received bytes are in place before the merge reads them
+        engine.merge(packed, totals[0][0], final, bases[0], True)
+        for r in range(1, world):  # in rank order: a run's first word is ORed into the word the run before ended in
+            engine.merge(stages[r], totals[r][0], final, bases[r], False)
+        nb = engine.seal(final, end_bit, adler)
+        assert nb == total_bytes, (nb, total_bytes)
     return total_bytes
