@@ -347,6 +347,9 @@ OTHER_CONFIGS = ("text64m", "raw4g", "records4g")  # the other single-GPU config
 
 def main():
     args = parse_args()
+    if os.environ.get("ZG_BENCH_HANG_DUMP"):  # seconds after which every thread's stack is printed and the run ends
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["ZG_BENCH_HANG_DUMP"]), exit=True)
     import torch
     import torch.distributed as dist
 

@@ -339,12 +339,12 @@ int run_front(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, MatchPara
     {
         const uint64_t nc = c1 - c0;
         const uint64_t spc = parse_subs_per_chunk(g.chunk_bytes), tpc = emit_tiles_per_chunk(g.chunk_bytes);
-        HIPCHK(c->flag.ensure(span + 64));
+        HIPCHK(c->flag.ensure(parse_flag_bytes(nc, g.chunk_bytes) + 64));
         HIPCHK(c->sub_exit.ensure(nc * spc * 4));
         HIPCHK(c->sub_exit2.ensure(nc * spc * 4));
         HIPCHK(c->merged.ensure(nc * spc));
         HIPCHK(c->tile_cnt.ensure(nc * tpc * 4));
-        LAUNCH(K_PARSE, launch_parse(g, c0, c1, c->match.as<uint32_t>(), ib0, c->flag.as<uint8_t>(), span,
+        LAUNCH(K_PARSE, launch_parse(g, c0, c1, c->match.as<uint32_t>(), ib0, c->flag.as<uint32_t>(),
                                      c->sub_exit.as<uint32_t>(), c->sub_exit2.as<uint32_t>(), c->merged.as<uint8_t>(),
                                      c->tile_cnt.as<uint32_t>(), c->tokens.as<uint32_t>(), bs, c->ntok.as<uint32_t>(),
                                      c->freq.as<uint32_t>(), &c->scalars.as<Scalars>()->status, c->stream));

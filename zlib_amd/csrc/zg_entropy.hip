@@ -13,7 +13,9 @@ namespace zg {
 // start.  It is resolved without walking the chunk serially:
 //   k_parse_spec   one lane per sub-tile of kParseSub positions walks the chain
 //                  from the sub-tile's first position (a guess for every
-//                  sub-tile but the first), flagging the positions it visits;
+//                  sub-tile but the first), flagging the positions it visits
+//                  (one bit per position: sub-tile g of the batch owns the
+//                  words [g * kParseSub / 32, (g + 1) * kParseSub / 32));
 //   k_parse_fix    one lane per sub-tile takes the previous sub-tile's exit as
 //                  its true entry, walks from there until it meets a flagged
 //                  position (greedy parses re-synchronise within a few units),
@@ -32,17 +34,21 @@ __device__ __forceinline__ uint32_t parse_step(const uint32_t *__restrict__ matc
 // byte each (coalesced reads; 255 stands for "255 or more: look it up"), one lane per sub-tile then walks its
 // chain through LDS, collecting the visited positions in a bit mask, and the workgroup writes the flags out as
 // whole words.  A sub-tile sits kSpecStride bytes from the next so that the walkers spread over the LDS banks.
-constexpr uint32_t kSpecRegion = 65536;                     // positions per workgroup
+#ifndef ZG_SPEC_REGION
+#define ZG_SPEC_REGION 65536
+#endif
+constexpr uint32_t kSpecRegion = ZG_SPEC_REGION;            // positions per workgroup
 constexpr uint32_t kSpecSubs = kSpecRegion / kParseSub;
 constexpr uint32_t kSpecStride = kParseSub + 4;
-constexpr uint32_t kSpecWords = kParseSub / 32 + 1;
+constexpr uint32_t kFlagWords = kParseSub / 32;  // flag words of a sub-tile
+constexpr uint32_t kSpecWords = kFlagWords + 1;
 constexpr uint32_t kSpecThreads = 256;
 
 __global__ __launch_bounds__(kSpecThreads) void k_parse_spec(uint64_t first, uint64_t end, uint64_t chunk_bytes,
                                                               const uint32_t *__restrict__ clen, uint32_t c0,
                                                               uint32_t n_chunks, uint32_t spc,
                                                               const uint32_t *__restrict__ match, uint64_t base,
-                                                              uint8_t *__restrict__ flag,
+                                                              uint32_t *__restrict__ flagw,
                                                               uint32_t *__restrict__ sub_exit) {
     __shared__ __attribute__((aligned(16))) uint8_t s_len[kSpecSubs * kSpecStride];
     __shared__ uint32_t s_bits[kSpecSubs * kSpecWords];
@@ -132,16 +138,11 @@ __global__ __launch_bounds__(kSpecThreads) void k_parse_spec(uint64_t first, uin
         }
     }
     __syncthreads();
-    for (uint32_t idx = tid * 4; idx < kSpecRegion; idx += kSpecThreads * 4) {
-        const uint32_t sub = idx / kParseSub, off = idx % kParseSub, n = s_n[sub];
-        if (off >= n) continue;
-        const uint32_t bits = (s_bits[sub * kSpecWords + (off >> 5)] >> (off & 31u)) & 0xFu;
-        uint8_t *f = flag + (s_s0[sub] + off - base);
-        if (off + 4 <= n && (reinterpret_cast<uintptr_t>(f) & 3) == 0) {
-            *reinterpret_cast<uint32_t *>(f) = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
-        } else {
-            for (uint32_t i = 0; i < 4 && off + i < n; i++) f[i] = (uint8_t)((bits >> i) & 1u);
-        }
+    // the flags leave as they are, a bit per position: the workgroup's sub-tiles own one run of words
+    const uint64_t n_sub = (uint64_t)n_chunks * spc;
+    for (uint32_t i = tid; i < kSpecSubs * kFlagWords; i += kSpecThreads) {
+        const uint32_t sub = i / kFlagWords, w = i % kFlagWords;
+        if (gid0 + sub < n_sub) flagw[(gid0 + sub) * kFlagWords + w] = s_bits[sub * kSpecWords + w];
     }
 }
 
@@ -149,58 +150,77 @@ __global__ __launch_bounds__(64) void k_parse_fix(uint64_t first, uint64_t end, 
         const uint32_t *__restrict__ clen, uint32_t c0,
                                                    uint32_t n_chunks, uint32_t spc,
                                                    const uint32_t *__restrict__ match, uint64_t base,
-                                                   uint8_t *__restrict__ flag, const uint32_t *__restrict__ sub_exit,
+                                                   uint32_t *__restrict__ flagw, const uint32_t *__restrict__ sub_exit,
                                                    uint32_t *__restrict__ sub_exit2, uint8_t *__restrict__ merged) {
+    // the flag words of the workgroup's 64 sub-tiles, worked on in LDS (a lane touches its own sub-tile's only)
+    __shared__ uint32_t s_f[64 * kSpecWords];
     const uint64_t gid = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    const uint64_t n_sub = (uint64_t)n_chunks * spc;
+    for (uint32_t i = threadIdx.x; i < 64 * kFlagWords; i += 64) {
+        const uint64_t g = (uint64_t)blockIdx.x * 64 + i / kFlagWords;
+        s_f[(i / kFlagWords) * kSpecWords + i % kFlagWords] = g < n_sub ? flagw[g * kFlagWords + i % kFlagWords] : 0u;
+    }
+    __syncthreads();
+    uint32_t *const mine = s_f + threadIdx.x * kSpecWords;
     const uint32_t ci = (uint32_t)(gid / spc), j = (uint32_t)(gid % spc);
-    if (ci >= n_chunks) return;
-    const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
-    const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
-    const uint64_t s0 = cs + (uint64_t)j * kParseSub;
-    const uint64_t k = (uint64_t)ci * spc + j;
-    if (j == 0) {
-        sub_exit2[k] = sub_exit[k];
-        merged[k] = 1;
-        return;
-    }
-    if (s0 >= ce) {
-        merged[k] = 1;
-        return;
-    }
-    const uint64_t s1 = (s0 + kParseSub < ce) ? s0 + kParseSub : ce;
-    const uint64_t e = cs + sub_exit[k - 1];  // true entry if every earlier sub-tile merged
-    if (e == s0) {
-        sub_exit2[k] = sub_exit[k];
-        merged[k] = 1;
-        return;
-    }
-    // where does the true chain meet the guessed one?
-    uint64_t t = e;
-    bool met = false;
-    while (t < s1) {
-        if (flag[t - base]) {
-            met = true;
-            break;
+    [&] {
+        if (ci >= n_chunks) return;
+        const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
+        const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
+        const uint64_t s0 = cs + (uint64_t)j * kParseSub;
+        const uint64_t k = gid;
+        if (j == 0) {
+            sub_exit2[k] = sub_exit[k];
+            merged[k] = 1;
+            return;
         }
-        t += parse_step(match, t - base);
+        if (s0 >= ce) {
+            merged[k] = 1;
+            return;
+        }
+        const uint64_t s1 = (s0 + kParseSub < ce) ? s0 + kParseSub : ce;
+        const uint64_t e = cs + sub_exit[k - 1];  // true entry if every earlier sub-tile merged
+        if (e == s0) {
+            sub_exit2[k] = sub_exit[k];
+            merged[k] = 1;
+            return;
+        }
+        // where does the true chain meet the guessed one?
+        uint64_t t = e;
+        bool met = false;
+        while (t < s1) {
+            const uint32_t off = (uint32_t)(t - s0);
+            if ((mine[off >> 5] >> (off & 31u)) & 1u) {
+                met = true;
+                break;
+            }
+            t += parse_step(match, t - base);
+        }
+        const uint64_t stop = met ? t : s1;  // flags from here on are already right (or there are none)
+        for (uint64_t q = s0; q < stop;) {   // drop the guessed prefix
+            const uint32_t off = (uint32_t)(q - s0);
+            mine[off >> 5] &= ~(1u << (off & 31u));
+            q += parse_step(match, q - base);
+        }
+        for (uint64_t u = e; u < stop;) {    // put the true prefix
+            const uint32_t off = (uint32_t)(u - s0);
+            mine[off >> 5] |= 1u << (off & 31u);
+            u += parse_step(match, u - base);
+        }
+        sub_exit2[k] = met ? sub_exit[k] : (uint32_t)(t - cs);
+        merged[k] = met ? 1 : 0;
+    }();
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 64 * kFlagWords; i += 64) {
+        const uint64_t g = (uint64_t)blockIdx.x * 64 + i / kFlagWords;
+        if (g < n_sub) flagw[g * kFlagWords + i % kFlagWords] = s_f[(i / kFlagWords) * kSpecWords + i % kFlagWords];
     }
-    const uint64_t stop = met ? t : s1;  // flags from here on are already right (or there are none)
-    for (uint64_t s = s0; s < stop;) {   // drop the guessed prefix
-        flag[s - base] = 0;
-        s += parse_step(match, s - base);
-    }
-    for (uint64_t u = e; u < stop;) {    // put the true prefix
-        flag[u - base] = 1;
-        u += parse_step(match, u - base);
-    }
-    sub_exit2[k] = met ? sub_exit[k] : (uint32_t)(t - cs);
-    merged[k] = met ? 1 : 0;
 }
 
 __global__ __launch_bounds__(64) void k_parse_check(uint64_t first, uint64_t end, uint64_t chunk_bytes,
         const uint32_t *__restrict__ clen, uint32_t c0,
                                                      uint32_t spc, const uint32_t *__restrict__ match, uint64_t base,
-                                                     uint8_t *__restrict__ flag, const uint32_t *__restrict__ sub_exit2,
+                                                     uint32_t *__restrict__ flagw, const uint32_t *__restrict__ sub_exit2,
                                                      const uint8_t *__restrict__ merged) {
     const uint32_t ci = blockIdx.x, lane = threadIdx.x;
     const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
@@ -215,15 +235,24 @@ __global__ __launch_bounds__(64) void k_parse_check(uint64_t first, uint64_t end
     }
     if (bad == 0xFFFFFFFFu || bad + 1 >= nsub) return;
     // everything after sub-tile `bad` was resolved from a wrong entry: redo it serially
-    const uint64_t r0 = cs + (uint64_t)(bad + 1) * kParseSub;
-    for (uint64_t p = r0 + lane; p < ce; p += 64) flag[p - base] = 0;
+    uint32_t *const fw = flagw + (uint64_t)ci * spc * kFlagWords;  // the chunk's flags: bit r = position cs + r
+    for (uint32_t w = (bad + 1) * kFlagWords + lane; w < nsub * kFlagWords; w += 64) fw[w] = 0;
     __syncthreads();
     if (lane == 0) {
         uint64_t p = cs + sub_exit2[(uint64_t)ci * spc + bad];
+        // (a sub-tile's exit lies past the sub-tile: only cleared words are written)
+        uint32_t wi = 0xFFFFFFFFu, word = 0;
         while (p < ce) {
-            flag[p - base] = 1;
+            const uint32_t r = (uint32_t)(p - cs);
+            if ((r >> 5) != wi) {
+                if (wi != 0xFFFFFFFFu) fw[wi] = word;
+                wi = r >> 5;
+                word = 0;
+            }
+            word |= 1u << (r & 31u);
             p += parse_step(match, p - base);
         }
+        if (wi != 0xFFFFFFFFu) fw[wi] = word;
     }
 }
 
@@ -233,22 +262,17 @@ __global__ __launch_bounds__(64) void k_parse_check(uint64_t first, uint64_t end
 // k_emit_count sums the flags per tile, k_emit_scan turns the sums into
 // offsets per chunk, k_emit writes the units and the histograms.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kEmitThreads) void k_emit_count(uint64_t first, uint64_t end, uint64_t chunk_bytes,
-                                                              const uint32_t *__restrict__ clen, uint32_t c0,
-                                                              uint32_t tpc,
-                                                              const uint8_t *__restrict__ flag, uint64_t base,
+__global__ __launch_bounds__(kEmitThreads) void k_emit_count(uint32_t spc, uint32_t tpc,
+                                                              const uint32_t *__restrict__ flagw,
                                                               uint32_t *__restrict__ tile_cnt) {
     __shared__ uint32_t s_red[kEmitThreads / 64];
     const uint32_t ci = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
-    const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
-    const uint64_t t0 = cs + (uint64_t)tile * kEmitTile;
+    // the tile's flags: kEmitTile / 32 words, zero past the chunk's end (and absent past the chunk's last sub-tile)
+    const uint32_t w0 = tile * (kEmitTile / 32), wn = spc * kFlagWords;
+    const uint32_t *fw = flagw + (uint64_t)ci * wn;
     uint32_t cnt = 0;
-    if (t0 < ce) {
-        const uint32_t tn = (uint32_t)((ce - t0 < kEmitTile) ? ce - t0 : kEmitTile);
-        const uint8_t *f = flag + (t0 - base);
-        for (uint32_t i = tid; i < tn; i += kEmitThreads) cnt += f[i];
-    }
+    for (uint32_t i = tid; i < kEmitTile / 32; i += kEmitThreads)
+        if (w0 + i < wn) cnt += (uint32_t)__builtin_popcount(fw[w0 + i]);
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
     if ((tid & 63) == 0) s_red[tid >> 6] = cnt;
     __syncthreads();
@@ -287,8 +311,8 @@ __global__ __launch_bounds__(256) void k_emit_scan(uint32_t tpc, uint32_t *__res
 
 __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict__ data, uint64_t first, uint64_t end,
                                                         uint64_t chunk_bytes, const uint32_t *__restrict__ clen,
-                                                        uint32_t c0, uint32_t tpc,
-                                                        const uint8_t *__restrict__ flag,
+                                                        uint32_t c0, uint32_t spc, uint32_t tpc,
+                                                        const uint32_t *__restrict__ flagw,
                                                         const uint32_t *__restrict__ match, uint64_t base,
                                                         const uint32_t *__restrict__ tile_off,
                                                         uint32_t *__restrict__ tokens, uint64_t tok_base,
@@ -305,23 +329,11 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict
     for (uint32_t i = tid; i < kTabStride; i += kEmitThreads) s_hist[i] = 0;
     constexpr uint32_t kPer = kEmitTile / kEmitThreads;  // consecutive positions per thread
     const uint32_t b0 = tid * kPer;
-    const uint8_t *f = flag + (t0 - base);
-    uint32_t fl = 0, cnt = 0;  // flags of my positions as a bit mask
-    if (kPer == 16 && b0 + kPer <= tn && (reinterpret_cast<uintptr_t>(f + b0) & 15) == 0) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(f + b0);
-        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (uint32_t i = 0; i < 16; i++)
-            if ((w[i >> 2] >> ((i & 3) * 8)) & 0xFFu) fl |= 1u << i;
-        cnt = (uint32_t)__builtin_popcount(fl);
-    } else {
-#pragma unroll
-        for (uint32_t i = 0; i < kPer; i++)
-            if (b0 + i < tn && f[b0 + i]) {
-                fl |= 1u << i;
-                cnt++;
-            }
-    }
+    static_assert(kPer == 16, "a thread takes half a flag word");
+    // flags of my positions as a bit mask (bits past the chunk's end are zero)
+    const uint32_t wi = (tile * kEmitTile + b0) >> 5;
+    uint32_t fl = wi < spc * kFlagWords ? (flagw[(uint64_t)ci * spc * kFlagWords + wi] >> (b0 & 16u)) & 0xFFFFu : 0u;
+    const uint32_t cnt = (uint32_t)__builtin_popcount(fl);
     s_scan[tid] = cnt;
     __syncthreads();
     for (uint32_t off = 1; off < kEmitThreads; off <<= 1) {
@@ -363,14 +375,14 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict
 }
 
 hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint32_t *match, uint64_t base,
-                        uint8_t *flag, uint64_t flag_bytes, uint32_t *sub_exit, uint32_t *sub_exit2, uint8_t *merged,
+                        uint32_t *flag, uint32_t *sub_exit, uint32_t *sub_exit2, uint8_t *merged,
                         uint32_t *tile_cnt, uint32_t *tokens, uint64_t tok_base, uint32_t *ntok, uint32_t *freq,
                         uint32_t *status, hipStream_t s) {
     if (c1 <= c0) return hipSuccess;
     const uint32_t nc = c1 - c0;
     const uint32_t spc = parse_subs_per_chunk(g.chunk_bytes);
     const uint32_t tpc = emit_tiles_per_chunk(g.chunk_bytes);
-    (void)flag_bytes;  // k_parse_spec writes the flag of every position of every chunk, set or not
+    // flag: parse_flag_bytes() bytes; k_parse_spec writes the word of every sub-tile of every chunk, set or not
     hipError_t e = hipMemsetAsync(freq, 0, (size_t)nc * kTabStride * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     const uint64_t lanes = (uint64_t)nc * spc;
@@ -381,11 +393,10 @@ hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint
                        match, base, flag, sub_exit, sub_exit2, merged);
     hipLaunchKernelGGL(k_parse_check, dim3(nc), dim3(64), 0, s, g.first, g.end, g.chunk_bytes, g.chunk_len, c0, spc, match,
                        base, flag, sub_exit2, merged);
-    hipLaunchKernelGGL(k_emit_count, dim3(tpc, nc), dim3(kEmitThreads), 0, s, g.first, g.end, g.chunk_bytes, g.chunk_len, c0,
-                       tpc, flag, base, tile_cnt);
+    hipLaunchKernelGGL(k_emit_count, dim3(tpc, nc), dim3(kEmitThreads), 0, s, spc, tpc, flag, tile_cnt);
     hipLaunchKernelGGL(k_emit_scan, dim3(nc), dim3(256), 0, s, tpc, tile_cnt, ntok);
     hipLaunchKernelGGL(k_emit, dim3(tpc, nc), dim3(kEmitThreads), 0, s, g.data, g.first, g.end, g.chunk_bytes, g.chunk_len,
-                       c0, tpc, flag, match, base, tile_cnt, tokens, tok_base, freq, status);
+                       c0, spc, tpc, flag, match, base, tile_cnt, tokens, tok_base, freq, status);
     return hipGetLastError();
 }
 

@@ -39,6 +39,10 @@ constexpr uint32_t kEmitThreads = 256;
 inline uint32_t parse_subs_per_chunk(uint64_t chunk_bytes) {
     return (uint32_t)((chunk_bytes + kParseSub - 1) / kParseSub);
 }
+// bytes of the parse's flags (a bit per position, whole sub-tiles) for n_chunks chunks
+inline uint64_t parse_flag_bytes(uint64_t n_chunks, uint64_t chunk_bytes) {
+    return n_chunks * parse_subs_per_chunk(chunk_bytes) * (kParseSub / 8);
+}
 inline uint32_t emit_tiles_per_chunk(uint64_t chunk_bytes) {
     return (uint32_t)((chunk_bytes + kEmitTile - 1) / kEmitTile);
 }
@@ -140,7 +144,7 @@ hipError_t launch_chunk_probe(const ChunkGrid &g, uint32_t c0, uint32_t c1, cons
                               const uint16_t *next5, uint64_t base, uint8_t *walk_chunk, hipStream_t s);
 // status: bit 2 is raised when the parse stands on a position whose match[] is kUnvisited
 hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint32_t *match, uint64_t base,
-                        uint8_t *flag, uint64_t flag_bytes, uint32_t *sub_exit, uint32_t *sub_exit2, uint8_t *merged,
+                        uint32_t *flag, uint32_t *sub_exit, uint32_t *sub_exit2, uint8_t *merged,
                         uint32_t *tile_cnt, uint32_t *tokens, uint64_t tok_base, uint32_t *ntok, uint32_t *freq,
                         uint32_t *status, hipStream_t s);
 hipError_t launch_histogram(const uint32_t *tokens, uint64_t n, uint32_t *freq, hipStream_t s);

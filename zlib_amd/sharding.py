@@ -194,10 +194,12 @@ def compress_sharded_overlapped(engine, dist, torch, rank: int, world: int, devi
     first, last_rank = rank == 0, rank == world - 1
     if scratch is None:
         scratch = {}
-    local = scratch.setdefault("piece", torch.zeros(5, dtype=torch.int64, device=device))
-    gathered = scratch.setdefault("pieces", torch.zeros(5 * world, dtype=torch.int64, device=device))
     packed = engine.packed
     staged = packed.is_cuda and dist.get_backend() not in ("nccl", "single")  # see compress_sharded
+    # RCCL gathers device tensors; the backends used to rehearse the path get the few integers in host memory
+    meta = "cpu" if staged else device
+    local = scratch.setdefault("piece", torch.zeros(5, dtype=torch.int64, device=meta))
+    gathered = scratch.setdefault("pieces", torch.zeros(5 * world, dtype=torch.int64, device=meta))
     engine.open(last_rank)
     done, got, totals = [False] * world, [0] * world, [None] * world
     mine = None  # (bits, adler) once this rank's last piece is out
@@ -247,9 +249,11 @@ def compress_sharded_overlapped(engine, dist, torch, rank: int, world: int, devi
                 done[r], totals[r] = True, (int(rows[r][1]), int(rows[r][2]), int(rows[r][4]))
     bases, end_bit, adler = stream_layout(totals)
     total_bytes = (end_bit + 7) // 8 + 4
+    if packed.is_cuda:
+        # RCCL's wait() orders streams, not the host: the received bytes must be in place before the merge (another
+        # stream) reads them, and a sender's bytes must have left before its next run overwrites the packed buffer
+        torch.cuda.current_stream(device).synchronize()
     if first:
-        if packed.is_cuda:
-            torch.cuda.current_stream(device).synchronize()  # the received bytes are in place before the merge reads them
         engine.merge(packed, totals[0][0], final, bases[0], True)
         for r in range(1, world):  # in rank order: a run's first word is ORed into the word the run before ended in
             engine.merge(stages[r], totals[r][0], final, bases[r], False)
