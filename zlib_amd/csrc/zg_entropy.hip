@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t parse_step(const uint32_t *__restrict__ matc
 // chain through LDS, collecting the visited positions in a bit mask, and the workgroup writes the flags out as
 // whole words.  A sub-tile sits kSpecStride bytes from the next so that the walkers spread over the LDS banks.
 #ifndef ZG_SPEC_REGION
-#define ZG_SPEC_REGION 65536
+#define ZG_SPEC_REGION 16384
 #endif
 constexpr uint32_t kSpecRegion = ZG_SPEC_REGION;            // positions per workgroup
 constexpr uint32_t kSpecSubs = kSpecRegion / kParseSub;
@@ -283,6 +283,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit_count(uint32_t spc, uint3
     }
 }
 
+constexpr uint32_t kScanFew = 16;  // chunks of up to this many tiles are scanned by a thread each
 __global__ __launch_bounds__(256) void k_emit_scan(uint32_t tpc, uint32_t *__restrict__ tile_cnt,
                                                     uint32_t *__restrict__ ntok) {
     __shared__ uint32_t s_part[256];
@@ -309,6 +310,21 @@ __global__ __launch_bounds__(256) void k_emit_scan(uint32_t tpc, uint32_t *__res
     if (tid == 255) ntok[ci] = s_part[255];
 }
 
+// the same for chunks of a few tiles (records): a thread per chunk instead of a workgroup
+__global__ __launch_bounds__(256) void k_emit_scan_few(uint32_t n_chunks, uint32_t tpc, uint32_t *__restrict__ tile_cnt,
+                                                        uint32_t *__restrict__ ntok) {
+    const uint32_t ci = blockIdx.x * 256 + threadIdx.x;
+    if (ci >= n_chunks) return;
+    uint32_t *tc = tile_cnt + (uint64_t)ci * tpc;
+    uint32_t run = 0;
+    for (uint32_t i = 0; i < tpc; i++) {
+        const uint32_t v = tc[i];
+        tc[i] = run;
+        run += v;
+    }
+    ntok[ci] = run;
+}
+
 __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict__ data, uint64_t first, uint64_t end,
                                                         uint64_t chunk_bytes, const uint32_t *__restrict__ clen,
                                                         uint32_t c0, uint32_t spc, uint32_t tpc,
@@ -325,7 +341,6 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict
     const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
     const uint64_t t0 = cs + (uint64_t)tile * kEmitTile;
     if (t0 >= ce) return;
-    const uint32_t tn = (uint32_t)((ce - t0 < kEmitTile) ? ce - t0 : kEmitTile);
     for (uint32_t i = tid; i < kTabStride; i += kEmitThreads) s_hist[i] = 0;
     constexpr uint32_t kPer = kEmitTile / kEmitThreads;  // consecutive positions per thread
     const uint32_t b0 = tid * kPer;
@@ -394,7 +409,10 @@ hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint
     hipLaunchKernelGGL(k_parse_check, dim3(nc), dim3(64), 0, s, g.first, g.end, g.chunk_bytes, g.chunk_len, c0, spc, match,
                        base, flag, sub_exit2, merged);
     hipLaunchKernelGGL(k_emit_count, dim3(tpc, nc), dim3(kEmitThreads), 0, s, spc, tpc, flag, tile_cnt);
-    hipLaunchKernelGGL(k_emit_scan, dim3(nc), dim3(256), 0, s, tpc, tile_cnt, ntok);
+    if (tpc <= kScanFew)
+        hipLaunchKernelGGL(k_emit_scan_few, dim3((nc + 255) / 256), dim3(256), 0, s, nc, tpc, tile_cnt, ntok);
+    else
+        hipLaunchKernelGGL(k_emit_scan, dim3(nc), dim3(256), 0, s, tpc, tile_cnt, ntok);
     hipLaunchKernelGGL(k_emit, dim3(tpc, nc), dim3(kEmitThreads), 0, s, g.data, g.first, g.end, g.chunk_bytes, g.chunk_len,
                        c0, spc, tpc, flag, match, base, tile_cnt, tokens, tok_base, freq, status);
     return hipGetLastError();
@@ -840,6 +858,21 @@ __global__ __launch_bounds__(256) void k_tile_scan(uint32_t max_tiles, const uin
     }
 }
 
+__global__ __launch_bounds__(256) void k_tile_scan_few(uint32_t n_chunks, uint32_t max_tiles,
+                                                        const uint32_t *__restrict__ ntok,
+                                                        uint32_t *__restrict__ tile_bits) {
+    const uint32_t ci = blockIdx.x * 256 + threadIdx.x;
+    if (ci >= n_chunks) return;
+    const uint32_t nt = (ntok[ci] + 1u + kEncTile - 1) / kEncTile;
+    uint32_t *tb = tile_bits + (uint64_t)ci * max_tiles;
+    uint32_t run = 0;
+    for (uint32_t i = 0; i < nt; i++) {
+        const uint32_t v = tb[i];
+        tb[i] = run;
+        run += v;
+    }
+}
+
 // absolute bit offset of every block: carry[0] is the offset of the first
 // block of this batch on entry and of the next batch on exit
 __global__ __launch_bounds__(256) void k_block_offsets(uint32_t n_chunks, const uint64_t *__restrict__ block_bits,
@@ -871,34 +904,41 @@ __global__ __launch_bounds__(256) void k_block_offsets(uint32_t n_chunks, const 
 // Record batches: every chunk is a zlib stream of its own, 2 header bytes + its block padded to a byte + 4
 // bytes of Adler-32 (reference src/compress.rs:51-86).  carry[0] is the byte offset of the batch's first
 // stream on entry and of the next batch's on exit.
-__global__ __launch_bounds__(256) void k_batch_offsets(uint32_t n_chunks, const uint64_t *__restrict__ block_bits,
-                                                        uint64_t *__restrict__ bit_off, uint64_t *carry,
-                                                        uint64_t *__restrict__ out_offsets) {
-    __shared__ uint64_t s_part[256];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n_chunks + 255) / 256;
-    const uint32_t lo = tid * per, hi = (lo + per < n_chunks) ? lo + per : n_chunks;
-    uint64_t s = 0;
-    for (uint32_t i = lo; i < hi && lo < n_chunks; i++) s += 6 + ((block_bits[i] + 7) >> 3);
-    s_part[tid] = s;
-    __syncthreads();
-    for (uint32_t off = 1; off < 256; off <<= 1) {
-        const uint64_t v = tid >= off ? s_part[tid - off] : 0ull;
+__global__ __launch_bounds__(1024) void k_batch_offsets(uint32_t n_chunks, const uint64_t *__restrict__ block_bits,
+                                                         uint64_t *__restrict__ bit_off, uint64_t *carry,
+                                                         uint64_t *__restrict__ out_offsets) {
+    // 1024 streams at a time, one per thread (neighbouring threads read neighbouring entries): a scan inside every
+    // wave, one over the 16 wave totals, the running total carried on
+    __shared__ uint64_t s_wave[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    uint64_t run = carry[0];
+    for (uint32_t i0 = 0; i0 < n_chunks; i0 += 1024) {
+        const uint32_t i = i0 + tid;
+        const uint64_t mine = i < n_chunks ? 6 + ((block_bits[i] + 7) >> 3) : 0;
+        uint64_t incl = mine;
+        for (uint32_t off = 1; off < 64; off <<= 1) {
+            const uint64_t up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) s_wave[wv] = incl;
         __syncthreads();
-        s_part[tid] += v;
+        uint64_t before = 0, total = 0;
+        for (uint32_t w = 0; w < 16; w++) {
+            const uint64_t t = s_wave[w];
+            before += w < wv ? t : 0;
+            total += t;
+        }
+        if (i < n_chunks) {
+            const uint64_t at = run + before + incl - mine;
+            out_offsets[i] = at;
+            bit_off[i] = (at + 2) * 8;
+        }
+        run += total;
         __syncthreads();
     }
-    const uint64_t base = carry[0];
-    uint64_t run = base + s_part[tid] - s;
-    for (uint32_t i = lo; i < hi && lo < n_chunks; i++) {
-        out_offsets[i] = run;
-        bit_off[i] = (run + 2) * 8;
-        run += 6 + ((block_bits[i] + 7) >> 3);
-    }
-    __syncthreads();
-    if (tid == 255) {
-        carry[0] = base + s_part[255];
-        out_offsets[n_chunks] = base + s_part[255];  // end of the last stream (the next batch rewrites it)
+    if (tid == 0) {
+        carry[0] = run;
+        out_offsets[n_chunks] = run;  // end of the last stream (the next batch rewrites it)
     }
 }
 __global__ __launch_bounds__(256) void k_batch_frame(uint32_t n_chunks, const uint64_t *__restrict__ block_bits,
@@ -920,7 +960,7 @@ __global__ __launch_bounds__(256) void k_batch_frame(uint32_t n_chunks, const ui
 hipError_t launch_batch_offsets(uint32_t n_chunks, const uint64_t *block_bits, uint64_t *bit_off, uint64_t *carry,
                                 uint64_t *out_offsets, hipStream_t s) {
     if (!n_chunks) return hipSuccess;
-    hipLaunchKernelGGL(k_batch_offsets, dim3(1), dim3(256), 0, s, n_chunks, block_bits, bit_off, carry, out_offsets);
+    hipLaunchKernelGGL(k_batch_offsets, dim3(1), dim3(1024), 0, s, n_chunks, block_bits, bit_off, carry, out_offsets);
     return hipGetLastError();
 }
 hipError_t launch_batch_frame(uint32_t n_chunks, const uint64_t *block_bits, const uint64_t *out_offsets,
@@ -942,7 +982,11 @@ hipError_t launch_tile_bits(uint32_t n_chunks, uint32_t max_tiles, const uint32_
 hipError_t launch_offsets(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *ntok, uint32_t *tile_bits,
                           const uint64_t *block_bits, uint64_t *bit_off, uint64_t *carry, hipStream_t s) {
     if (!n_chunks) return hipSuccess;
-    hipLaunchKernelGGL(k_tile_scan, dim3(n_chunks), dim3(256), 0, s, max_tiles, ntok, tile_bits);
+    if (max_tiles <= kScanFew)
+        hipLaunchKernelGGL(k_tile_scan_few, dim3((n_chunks + 255) / 256), dim3(256), 0, s, n_chunks, max_tiles, ntok,
+                           tile_bits);
+    else
+        hipLaunchKernelGGL(k_tile_scan, dim3(n_chunks), dim3(256), 0, s, max_tiles, ntok, tile_bits);
     hipLaunchKernelGGL(k_block_offsets, dim3(1), dim3(256), 0, s, n_chunks, block_bits, bit_off, carry);
     return hipGetLastError();
 }

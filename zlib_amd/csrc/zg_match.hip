@@ -265,7 +265,7 @@ extern "C" int zg_index_debug_phases(unsigned long long *out) {
 // each), which leave in 16-byte stores.
 constexpr uint32_t kIdxStageBytes = kIdxSpan + 256;
 constexpr uint32_t kIdxLdsWordsStream = kIdxRBuckets + 2 * kIdxStageBytes / 4 + 2 * kIdxSpan / 2;
-constexpr uint32_t kIdxLdsWordsIso = kIdxRBuckets;
+constexpr uint32_t kIdxLdsWordsIso = kIdxRBuckets + kIdxStageBytes / 4;  // with slots: the table and one region of bytes
 
 template <int K, bool kIso>
 __device__ __forceinline__ void index_r_segment(uint32_t *s_mem, uint32_t seg, uint32_t seg_len,
@@ -489,32 +489,112 @@ __device__ __forceinline__ void index_r_segment(uint32_t *s_mem, uint32_t seg, u
     auto is_full = [&](uint32_t q) { return q + kIdxSpan <= q_top && q + kIdxSpan + window + 72u <= n_rel; };
 
     if constexpr (kIso) {
-        // Slots (records): the general forms, the keys of the next group loaded while this one is handled.
-        // relg / reln: offset of a group's first position inside its slot, for the group being handled / the one
-        // whose keys are being loaded
+        // Slots (records).  No group answers a far[] a window above it when the slots are shorter than the window;
+        // a slot's far[] are read from the table when the walk has reached the slot's first position.  The bytes of
+        // a group come in by one 16-byte and one 4-byte load per lane, a group ahead of their use, and the keys are
+        // cut out of them in LDS (a key load per lane and instruction, unaligned, kept the address unit busy longer
+        // than everything else took); groups at the edges of the view load their keys lane by lane.
+        // relg: offset of the group's first position inside its slot
         auto rel_down = [&](uint32_t rel) { return rel >= kIdxSpan ? rel - kIdxSpan : rel + iso_bytes - kIdxSpan; };
         uint32_t relg = (uint32_t)((a0 - iso_first + (uint64_t)(n_groups - 1u) * kIdxSpan) % iso_bytes);
-        uint32_t reln = relg;
-        GroupKeys buf;
-        {
-            const uint32_t qn = (n_groups - 1u) * kIdxSpan;
-            load_keys(buf, qn, !look_none(qn, slot_end_of(qn, reln)));
-            reln = rel_down(reln);
-        }
+        uint8_t *const s_stage = reinterpret_cast<uint8_t *>(s_mem + kIdxRBuckets);
+        const uint32_t mis_a = (uint32_t)(reinterpret_cast<uintptr_t>(dseg) & 15u);  // groups start on multiples of kIdxSpan from a0
+        // the staged loads start up to 15 bytes below the group's first byte and end up to 272 behind its last
+        auto stageable = [&](uint32_t q) {
+            return q + kIdxSpan <= q_top && q + kIdxSpan + 320u <= n_rel && (q != 0u || a0 >= 16u);
+        };
+        struct RawA {
+            uint4 a;
+            uint32_t at;
+        };
+        auto prefetch_a = [&](RawA &r, uint32_t q) __attribute__((always_inline)) {
+            const uint8_t *const pa = dseg + q - mis_a;
+            r.a = *reinterpret_cast<const uint4 *>(pa + lane * 16u);
+            r.at = *reinterpret_cast<const uint32_t *>(pa + kIdxSpan + lane * 4u);
+        };
+        auto stage_a = [&](const RawA &r) __attribute__((always_inline)) {
+            asm volatile("" ::: "memory");  // the typed reads before are of the bytes that were here
+            *reinterpret_cast<uint4 *>(s_stage + lane * 16u) = r.a;
+            *reinterpret_cast<uint32_t *>(s_stage + kIdxSpan + lane * 4u) = r.at;
+            asm volatile("" ::: "memory");  // the typed reads below are of these bytes
+        };
+        // insert-mode keys of the staged group: instruction k, lane l holds position qg + kIdxSpan - 1 - (64 k + l)
+        auto keys_from_stage = [&](GroupKeys &buf) __attribute__((always_inline)) {
+            const uint32_t kb0 = mis_a + (kIdxSpan - 1u) - lane;
+            const uint32_t *const wp = reinterpret_cast<const uint32_t *>(s_stage + (kb0 & ~3u) - 64u * (kIdxGroup - 1u));
+            const uint32_t sh = kb0 & 3u;
+#pragma unroll
+            for (int k = 0; k < (int)kIdxGroup; k++) {
+                const uint32_t d0 = wp[((int)kIdxGroup - 1 - k) * 16], d1 = wp[((int)kIdxGroup - 1 - k) * 16 + 1];
+                buf.k[k].a = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                buf.k[k].b = d1 >> (sh * 8u);  // (its lowest byte is the key's fifth)
+                buf.k[kIdxGroup + k] = buf.k[k];
+            }
+        };
+        // far[] of the staged group at pb, positions ascending with the lane, from the table as it stands
+        auto sweep_staged = [&](uint32_t pb, uint32_t pe) __attribute__((always_inline)) {
+            const uint32_t kb0 = mis_a + lane;
+            const uint32_t *const wp = reinterpret_cast<const uint32_t *>(s_stage + (kb0 & ~3u));
+            const uint32_t sh = kb0 & 3u;
+            uint32_t h[kIdxGroup];
+#pragma unroll
+            for (int j = 0; j < (int)kIdxGroup; j++) {
+                const uint32_t d0 = wp[j * 16], d1 = wp[j * 16 + 1];
+                h[j] = key_hash<K>(__builtin_amdgcn_alignbyte(d1, d0, sh), K > 4 ? d1 >> (sh * 8u) : 0u) >> (32 - kIdxRBits);
+            }
+#pragma unroll
+            for (int j = 0; j < (int)kIdxGroup; j++) h[j] = s_head[h[j]];
+#pragma unroll
+            for (int j = 0; j < (int)kIdxGroup; j++) {
+                const uint32_t p = pb + (uint32_t)j * 64 + lane;
+                if (p >= q_far && p < pe) st16(far_seg, p, h[j] ? p - (kEnc - h[j]) : 0u);
+            }
+        };
+        constexpr uint32_t kSweepAhead = 3;  // groups of a slot whose bytes are fetched ahead for the sweep
+        RawA raw = RawA{make_uint4(0, 0, 0, 0), 0u};
+        if (stageable((n_groups - 1u) * kIdxSpan)) prefetch_a(raw, (n_groups - 1u) * kIdxSpan);
         for (uint32_t g = n_groups; g > 0;) {
             --g;
             const uint32_t qg = g * kIdxSpan, qn = qg - kIdxSpan;
             const uint32_t slot_end = slot_end_of(qg, relg);
             const bool sweep = relg == 0u;
-            const bool look_n = g >= 1u && !look_none(qn, slot_end_of(qn, reln));
             const bool n0 = qg >= q_b || qg + kIdxSpan <= q_a, n1 = qg >= q_a && qg + kIdxSpan <= q_b;
-            GroupKeys cur;
+            const bool l0 = look_none(qg, slot_end);
+            const bool st_g = l0 && stageable(qg), st_n = g >= 1u && stageable(qn);
+            // the sweep of a slot: its groups above this one come in again (the staged sweep needs every one of them
+            // well inside the view and the slot made of whole groups)
+            uint32_t pe = qg + reach < q_b ? qg + reach : q_b;
+            pe = pe < slot_end ? pe : slot_end;
+            const uint32_t n_sw = sweep && pe > qg ? (pe - qg + kIdxSpan - 1u) / kIdxSpan : 0u;
+            const bool sw_staged = sweep && st_g && n_sw >= 1u && n_sw <= kSweepAhead + 1u && qg >= q_far &&
+                                   stageable(qg + (n_sw - 1u) * kIdxSpan);
+            RawA sw[kSweepAhead];
 #pragma unroll
-            for (int i = 0; i < 2 * (int)kIdxGroup; i++) cur.k[i] = buf.k[i];
-            load_keys(buf, qn, look_n);
-            general(cur, qg, slot_end, sweep, is_full(qg), n0, n1, look_none(qg, slot_end), look_all(qg, slot_end));
+            for (uint32_t j = 0; j < kSweepAhead; j++) {
+                sw[j] = RawA{make_uint4(0, 0, 0, 0), 0u};
+                if (sw_staged && j + 1u < n_sw) prefetch_a(sw[j], qg + (j + 1u) * kIdxSpan);
+            }
+            GroupKeys cur;
+            if (st_g) {
+                stage_a(raw);
+                if (st_n) prefetch_a(raw, qn);
+                keys_from_stage(cur);
+            } else {
+                if (st_n) prefetch_a(raw, qn);
+                load_keys(cur, qg, !l0);
+            }
+            general(cur, qg, slot_end, sweep && !sw_staged, is_full(qg), n0, n1, l0, look_all(qg, slot_end));
+            if (sw_staged) {
+                sweep_staged(qg, pe);  // this group's bytes are still staged
+#pragma unroll
+                for (uint32_t j = 0; j < kSweepAhead; j++) {
+                    if (j + 1u < n_sw) {
+                        stage_a(sw[j]);
+                        sweep_staged(qg + (j + 1u) * kIdxSpan, pe);
+                    }
+                }
+            }
             relg = rel_down(relg);
-            reln = rel_down(reln);
         }
     } else {
         // No slots: the common case -- every key inside the view, every look-up wanted, the whole group owned or not
