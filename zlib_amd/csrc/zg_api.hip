@@ -58,7 +58,6 @@ struct Scalars {
     uint32_t status;      // bit 0: output capacity exceeded, bit 1: index exchange out of order, bit 2: the parse
                           // stood on a position the walk kernel had not searched
     uint32_t pad;
-    uint64_t unused_carry;  // sink for the block-offset scan where only the tile scan is wanted
 };
 
 // Scratch of zg_adler32_device_noalloc: a fixed array in the code object, of which every GPU the library runs
@@ -770,9 +769,8 @@ int compress_batch_once(zg_ctx *c, const uint8_t *d_in, size_t stride, const uin
         LAUNCH(K_TILEBITS, launch_tile_bits(c1 - c0, max_tiles, c->tokens.as<uint32_t>(), g, c0, bs,
                                             c->ntok.as<uint32_t>(), c->tab.as<uint32_t>(), c->tile_bits.as<uint32_t>(),
                                             c->stream));
-        LAUNCH(K_OFFSETS, launch_offsets(c1 - c0, max_tiles, c->ntok.as<uint32_t>(), c->tile_bits.as<uint32_t>(),
-                                         c->block_bits.as<uint64_t>(), c->bit_off.as<uint64_t>(), &sc->unused_carry,
-                                         c->stream));
+        LAUNCH(K_OFFSETS, launch_tile_scan(c1 - c0, max_tiles, c->ntok.as<uint32_t>(), c->tile_bits.as<uint32_t>(),
+                                           c->stream));
         LAUNCH(K_OFFSETS, launch_batch_offsets(c1 - c0, c->block_bits.as<uint64_t>(), c->bit_off.as<uint64_t>(),
                                                &sc->carry, d_off + c0, c->stream));
         LAUNCH(K_ENCODE, launch_encode(c1 - c0, max_tiles, c->tokens.as<uint32_t>(), g, c0, bs, c->ntok.as<uint32_t>(),
@@ -1030,8 +1028,9 @@ int zg_decompress_blocks_device(zg_ctx *ctx, const void *d_stream, size_t stream
         c->err = inflate_message(hst);
         return ZG_ERR_DATA;
     }
-    // tokens and units are kept for a pass of blocks at a time (2 GiB of output), the windows for all blocks
-    const uint32_t pass_blocks = (uint32_t)std::min<uint64_t>(n_blocks, std::max<uint64_t>(1, ((uint64_t)2 << 30) / chunk_bytes));
+    // tokens and units are kept for a pass of blocks at a time (4 GiB of output: 16 blocks of 1 MiB per CU, all of
+    // them decoding at once), the windows for all blocks
+    const uint32_t pass_blocks = (uint32_t)std::min<uint64_t>(n_blocks, std::max<uint64_t>(1, ((uint64_t)4 << 30) / chunk_bytes));
     HIPCHK(c->inf_tok.ensure((size_t)pass_blocks * inflate_tok_stride(chunk_bytes) * sizeof(uint32_t)));
     HIPCHK(c->inf_ntok.ensure((size_t)pass_blocks * sizeof(uint32_t)));
     HIPCHK(c->inf_units.ensure(((size_t)pass_blocks * chunk_bytes + 64) * sizeof(uint16_t)));

@@ -907,14 +907,20 @@ __global__ __launch_bounds__(256) void k_block_offsets(uint32_t n_chunks, const 
 __global__ __launch_bounds__(1024) void k_batch_offsets(uint32_t n_chunks, const uint64_t *__restrict__ block_bits,
                                                          uint64_t *__restrict__ bit_off, uint64_t *carry,
                                                          uint64_t *__restrict__ out_offsets) {
-    // 1024 streams at a time, one per thread (neighbouring threads read neighbouring entries): a scan inside every
-    // wave, one over the 16 wave totals, the running total carried on
+    // 8192 streams at a time, eight neighbours per thread: a scan inside every wave, one over the 16 wave totals,
+    // the running total carried on
+    constexpr uint32_t kPer = 8;
     __shared__ uint64_t s_wave[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     uint64_t run = carry[0];
-    for (uint32_t i0 = 0; i0 < n_chunks; i0 += 1024) {
-        const uint32_t i = i0 + tid;
-        const uint64_t mine = i < n_chunks ? 6 + ((block_bits[i] + 7) >> 3) : 0;
+    for (uint32_t i0 = 0; i0 < n_chunks; i0 += 1024 * kPer) {
+        const uint32_t i = i0 + tid * kPer;
+        uint64_t len[kPer], mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++) {
+            len[k] = i + k < n_chunks ? 6 + ((block_bits[i + k] + 7) >> 3) : 0;
+            mine += len[k];
+        }
         uint64_t incl = mine;
         for (uint32_t off = 1; off < 64; off <<= 1) {
             const uint64_t up = __shfl_up(incl, off);
@@ -928,10 +934,14 @@ __global__ __launch_bounds__(1024) void k_batch_offsets(uint32_t n_chunks, const
             before += w < wv ? t : 0;
             total += t;
         }
-        if (i < n_chunks) {
-            const uint64_t at = run + before + incl - mine;
-            out_offsets[i] = at;
-            bit_off[i] = (at + 2) * 8;
+        uint64_t at = run + before + incl - mine;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++) {
+            if (i + k < n_chunks) {
+                out_offsets[i + k] = at;
+                bit_off[i + k] = (at + 2) * 8;
+            }
+            at += len[k];
         }
         run += total;
         __syncthreads();
@@ -979,14 +989,21 @@ hipError_t launch_tile_bits(uint32_t n_chunks, uint32_t max_tiles, const uint32_
                        g.chunk_bytes, c0, tok_base, ntok, tab, tile_bits);
     return hipGetLastError();
 }
-hipError_t launch_offsets(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *ntok, uint32_t *tile_bits,
-                          const uint64_t *block_bits, uint64_t *bit_off, uint64_t *carry, hipStream_t s) {
+hipError_t launch_tile_scan(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *ntok, uint32_t *tile_bits,
+                            hipStream_t s) {
     if (!n_chunks) return hipSuccess;
     if (max_tiles <= kScanFew)
         hipLaunchKernelGGL(k_tile_scan_few, dim3((n_chunks + 255) / 256), dim3(256), 0, s, n_chunks, max_tiles, ntok,
                            tile_bits);
     else
         hipLaunchKernelGGL(k_tile_scan, dim3(n_chunks), dim3(256), 0, s, max_tiles, ntok, tile_bits);
+    return hipGetLastError();
+}
+hipError_t launch_offsets(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *ntok, uint32_t *tile_bits,
+                          const uint64_t *block_bits, uint64_t *bit_off, uint64_t *carry, hipStream_t s) {
+    if (!n_chunks) return hipSuccess;
+    const hipError_t e = launch_tile_scan(n_chunks, max_tiles, ntok, tile_bits, s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_block_offsets, dim3(1), dim3(256), 0, s, n_chunks, block_bits, bit_off, carry);
     return hipGetLastError();
 }

@@ -536,29 +536,29 @@ __device__ __forceinline__ uint32_t d_entry(uint32_t sym, uint32_t code_len) {
     return code_len | (dst_extra(sym) << 4) | (dst_base(sym) << 8);
 }
 
-// Bits of the stream for a decoder that the whole wave runs in step.  `in` is four-byte aligned; bytes from
-// in_bytes on read as zero.
+// Bits of the stream for a decoder that the whole wave runs in step.  `in` is four-byte aligned and the block's
+// first word; offsets are 32-bit (a block's bits are far fewer than 2^32 bytes; 64-bit comparisons have no scalar
+// form).  Bytes from `lim` on read as zero.
 struct WaveBits {
     const uint8_t *in;
-    uint64_t in_bytes;
-    uint64_t pos;    // bytes taken into buf so far (a multiple of four); the word at pos is already in nextw
+    uint32_t lim;    // bytes of the stream from `in` on (saturated)
+    uint32_t pos;    // bytes taken into buf so far (a multiple of four); the word at pos is already in nextw
     uint64_t buf;
     uint32_t cnt, nextw;
-    __device__ __forceinline__ uint32_t word(uint64_t p) const {
-        if (p + 4 <= in_bytes) return *reinterpret_cast<const uint32_t *>(in + p);  // a scalar load: not waited for here
+    __device__ __forceinline__ uint32_t word(uint32_t p) const {
+        if (__builtin_expect(p + 4u <= lim, 1)) return *reinterpret_cast<const uint32_t *>(in + p);  // a scalar load: not waited for here
         uint32_t v = 0;
         for (uint32_t k = 0; k < 4; k++)
-            if (p + k < in_bytes) v |= (uint32_t)in[p + k] << (8 * k);
+            if (p + k < lim) v |= (uint32_t)in[p + k] << (8 * k);
         return uni(v);
     }
-    __device__ __forceinline__ void start(uint64_t bit) {
-        pos = (bit >> 3) & ~(uint64_t)3;
-        const uint32_t skip = (uint32_t)(bit - pos * 8);
+    __device__ __forceinline__ void start(uint32_t skip_bits) {  // skip_bits < 32
+        pos = 0;
         buf = 0;
         cnt = 0;
-        nextw = word(pos);
+        nextw = word(0);
         fill();
-        drop(skip);
+        drop(skip_bits);
     }
     __device__ __forceinline__ void fill() {  // at least 33 bits in buf afterwards
         if (cnt <= 32) {
@@ -572,7 +572,7 @@ struct WaveBits {
         buf >>= n;
         cnt -= n;
     }
-    __device__ __forceinline__ uint64_t bit_pos() const { return pos * 8 - cnt; }  // of the next bit
+    __device__ __forceinline__ uint64_t bit_pos() const { return (uint64_t)pos * 8 - cnt; }  // of the next bit, from `in`
 };
 
 // code counts per length 1..15 in registers, the same in every lane
@@ -760,16 +760,20 @@ __global__ __launch_bounds__(kInfLanes) void k_decode_tokens(const uint8_t *__re
     WaveCounts llc, dc;
     llc.load(s_t.ll_cnt);
     dc.load(s_t.d_cnt);
+    const uint64_t hdr_bit = (uint64_t)uni((uint32_t)s_bit) | ((uint64_t)uni((uint32_t)(s_bit >> 32)) << 32);
+    const uint64_t w0 = (hdr_bit >> 3) & ~(uint64_t)3;  // the word the first symbol begins in
     WaveBits b;
-    b.in = in;
-    b.in_bytes = in_bytes;
-    b.start((uint64_t)uni((uint32_t)s_bit) | ((uint64_t)uni((uint32_t)(s_bit >> 32)) << 32));
-    uint32_t st = INF_OK, nt = 0, tokv = 0;
-    uint64_t n = 0;
+    b.in = in + w0;
+    b.lim = in_bytes - w0 < 0xFFFFFFF0ull ? (uint32_t)(in_bytes - w0) : 0xFFFFFFF0u;
+    b.start((uint32_t)(hdr_bit - w0 * 8));
+    // units so far and the most a distance may reach back, in 32 bits (a block gives at most 2^28 bytes)
+    const uint32_t want32 = (uint32_t)want;
+    const uint32_t back = blk == 0 ? 0u : (out0 < 32768u ? (uint32_t)out0 : 32768u);
+    uint32_t st = INF_OK, nt = 0, tokv = 0, n = 0;
     for (;;) {
         b.fill();
         uint32_t e = uni(s_t.ll_lut[(uint32_t)b.buf & ((1u << kLlBits) - 1u)]);
-        if (e != 0) {
+        if (__builtin_expect(e != 0, 1)) {
             b.drop(e & 15u);
         } else {
             const int sy = wave_slow_sym(b, llc, s_t.ll_sym);
@@ -783,19 +787,19 @@ __global__ __launch_bounds__(kInfLanes) void k_decode_tokens(const uint8_t *__re
         if ((e >> 30) == 0) {
             t = (e >> 8) & 0xFFu;
             n += 1;
-        } else if (e & kEntEob) {
+        } else if (__builtin_expect((e & kEntEob) != 0, 0)) {
             break;
         } else {
             const uint32_t xb = (e >> 4) & 15u;
             const uint32_t len = ((e >> 8) & 0x1FFu) + ((uint32_t)b.buf & ((1u << xb) - 1u));
-            if (((e >> 8) & 0x1FFu) == 0) {
+            if (__builtin_expect(((e >> 8) & 0x1FFu) == 0, 0)) {
                 st = INF_BAD_SYMBOL;
                 break;
             }
             b.drop(xb);
             b.fill();
             uint32_t f = uni(s_t.d_lut[(uint32_t)b.buf & ((1u << kDBits) - 1u)]);
-            if (f != 0) {
+            if (__builtin_expect(f != 0, 1)) {
                 b.drop(f & 15u);
             } else {
                 const int ds = wave_slow_sym(b, dc, s_t.d_sym);
@@ -807,34 +811,39 @@ __global__ __launch_bounds__(kInfLanes) void k_decode_tokens(const uint8_t *__re
             }
             const uint32_t yb = (f >> 4) & 15u;
             const uint32_t dist = (f >> 8) + ((uint32_t)b.buf & ((1u << yb) - 1u));
-            if ((f >> 8) == 0) {
+            if (__builtin_expect((f >> 8) == 0, 0)) {
                 st = INF_BAD_SYMBOL;
                 break;
             }
             b.drop(yb);
-            // before the start of the stream, or more than a window back
-            if (dist > n + (blk ? 32768u : 0u) || (blk && dist > n && out0 < dist - n)) {
+            if (__builtin_expect(dist > n + back, 0)) {  // before the start of the stream, or more than a window back
                 st = INF_BAD_DISTANCE;
                 break;
             }
             t = kTokMatch | ((len - 3u) << 15) | (dist - 1u);
             n += len;
         }
-        if (n > want) {  // more than the block's share of the output
-            st = INF_OVERFLOW;
-            break;
-        }
         tokv = lane == (nt & 63u) ? t : tokv;
         nt++;
-        if ((nt & 63u) == 0) tk[nt - 64u + lane] = tokv;
+        if ((nt & 63u) == 0) {
+            // More than the block's share of the output?  Looked at once per group: a token gives a unit at least,
+            // so the tokens stay within the block's room for them.
+            if (__builtin_expect(n > want32, 0)) {
+                st = INF_OVERFLOW;
+                break;
+            }
+            tk[nt - 64u + lane] = tokv;
+        }
     }
-    if (nt & 63u) tk[(nt & ~63u) + lane] = tokv;  // the lanes behind the last token hold old ones: never read
-    if (st == INF_OK && n != want) st = INF_TRUNCATED;  // the block ended short of its share
+    if (st == INF_OK && n > want32) st = INF_OVERFLOW;
+    if (st == INF_OK && (nt & 63u)) tk[(nt & ~63u) + lane] = tokv;  // the lanes behind the last token hold old ones: never read
+    if (st == INF_OK && n != want32) st = INF_TRUNCATED;  // the block ended short of its share
     // where the block ended: the next block must begin there (the last one: the trailer, after padding)
-    if (st == INF_OK && blk + 1 < n_blocks && b.bit_pos() != bit_off[blk + 1] + bit_shift) st = INF_BAD_BLOCK;
+    const uint64_t end_bit = w0 * 8 + b.bit_pos();
+    if (st == INF_OK && blk + 1 < n_blocks && end_bit != bit_off[blk + 1] + bit_shift) st = INF_BAD_BLOCK;
     if (lane == 0) {
         if (blk + 1 == n_blocks) {  // behind the statuses: the bit at which the last block ended
-            const uint64_t e = b.bit_pos() - bit_shift;
+            const uint64_t e = end_bit - bit_shift;
             status[n_blocks] = (uint32_t)e;
             status[n_blocks + 1] = (uint32_t)(e >> 32);
         }

@@ -154,6 +154,8 @@ hipError_t launch_huffman(uint32_t n_chunks, int strategy, const uint32_t *freq,
 hipError_t launch_tile_bits(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *tokens, const ChunkGrid &g,
                             uint32_t c0, uint64_t tok_base, const uint32_t *ntok, const uint32_t *tab,
                             uint32_t *tile_bits, hipStream_t s);
+hipError_t launch_tile_scan(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *ntok, uint32_t *tile_bits,
+                            hipStream_t s);
 hipError_t launch_offsets(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *ntok, uint32_t *tile_bits,
                           const uint64_t *block_bits, uint64_t *bit_off, uint64_t *carry, hipStream_t s);
 hipError_t launch_zero_seams(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *ntok, const uint32_t *hdr_bits,
