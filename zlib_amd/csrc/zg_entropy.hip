@@ -521,7 +521,12 @@ __device__ void wave_huff_lengths(const uint32_t *freq, int n, int max_bits, uin
         __syncthreads();
         return;
     }
-    if (lane == 0) huff_merge(freq, m, w);
+    // the weights in sorted order, by all lanes (one lane loading them one by one waited a memory latency each)
+    for (int i = (int)lane; i < m; i += 64) w.weight[i] = freq[w.sorted[i]];
+    __syncthreads();
+    // (the merge on one lane: run by the whole wave in step, its state in scalar registers, it was slower -- a CU has
+    // one scalar unit for its eighteen waves of this kernel and four vector units)
+    if (lane == 0) huff_merge_loaded(m, w);
     __syncthreads();
     const int root = 2 * m - 2;
     uint32_t mx = 0;

@@ -119,8 +119,8 @@ ZG_HD inline int huff_sort(const uint32_t *freq, int n, uint8_t *len, HuffWork &
 
 // step 2 (m >= 2): two-queue Huffman over the sorted leaves 0..m-1; internal nodes m..2m-2 in creation order.
 // The heads of both queues are kept in locals so that an iteration does not wait on memory it just wrote.
-ZG_HD inline void huff_merge(const uint32_t *freq, int m, HuffWork &w) {
-    for (int i = 0; i < m; i++) w.weight[i] = freq[w.sorted[i]];
+// (the weights of the sorted leaves are in w.weight[0..m))
+ZG_HD inline void huff_merge_loaded(int m, HuffWork &w) {
     int li = 0, ii = m, ni = m;
     uint32_t lw = w.weight[0];  // weight of the next leaf (valid while li < m)
     uint32_t iw = 0;            // weight of the next internal node (valid while ii < ni)
@@ -145,6 +145,11 @@ ZG_HD inline void huff_merge(const uint32_t *freq, int m, HuffWork &w) {
         w.parent[pick[1]] = (uint16_t)ni;
         ni++;
     }
+}
+
+ZG_HD inline void huff_merge(const uint32_t *freq, int m, HuffWork &w) {
+    for (int i = 0; i < m; i++) w.weight[i] = freq[w.sorted[i]];
+    huff_merge_loaded(m, w);
 }
 
 // step 3: depth of every node top-down (parents have larger indices), reusing weight[] for the depth
