@@ -12,11 +12,11 @@ for WL in mixed8g text64m raw4g records4g text256m binary256m random256m; do
   echo "== bench line $WL"
   timeout -k 10 400 python3 bench.py --no-cpu-baseline --no-others --steps 5 --warmup 1 --workload $WL > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err
 done
-for WL in mixed8g text64m raw4g records256m; do
+for WL in mixed8g text64m raw4g records256m records4g; do
   echo "== stats $WL"
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -o r -- $B --steps 3 --warmup 1 --workload $WL > $OUT/stats_$WL.log 2>&1
 done
-for WL in mixed8g text64m raw4g; do
+for WL in mixed8g text64m raw4g records4g; do
   echo "== traffic $WL"
   timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$WL -- $B --steps 1 --warmup 0 --workload $WL > $OUT/fetch_$WL.log 2>&1
   timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$WL -- $B --steps 1 --warmup 0 --workload $WL > $OUT/write_$WL.log 2>&1

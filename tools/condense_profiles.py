@@ -57,7 +57,7 @@ for wl, t in traffic.items():  # mean kernel durations of the same workload, for
 json.dump({"note": "per launch, one bench step; hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (FETCH_SIZE counts wide reads at half "
                    "their size on gfx950); separate rocprofv3 --pmc passes", "workloads": traffic},
           open(f"profiles/{tag}_traffic.json", "w"), indent=1)
-for wl in ("mixed8g", "text64m"):
+for wl in ("mixed8g", "text64m", "records4g"):
     if not os.path.isdir(f"{src}/sqa_{wl}"):
         continue
     sa, _ = pmc(f"{src}/sqa_{wl}")
