@@ -334,55 +334,87 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict
                                                         uint32_t *__restrict__ tokens, uint64_t tok_base,
                                                         uint32_t *__restrict__ freq, uint32_t *__restrict__ status) {
     __shared__ uint32_t s_hist[kTabStride];
-    __shared__ uint32_t s_scan[kEmitThreads];
+    __shared__ uint32_t s_wave[kEmitThreads / 64];
     __shared__ uint32_t s_tok[kEmitTile];
     const uint32_t ci = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
     const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
     const uint64_t t0 = cs + (uint64_t)tile * kEmitTile;
     if (t0 >= ce) return;
+    const uint32_t tn = (uint32_t)((ce - t0 < kEmitTile) ? ce - t0 : kEmitTile);
     for (uint32_t i = tid; i < kTabStride; i += kEmitThreads) s_hist[i] = 0;
     constexpr uint32_t kPer = kEmitTile / kEmitThreads;  // consecutive positions per thread
     const uint32_t b0 = tid * kPer;
     static_assert(kPer == 16, "a thread takes half a flag word");
     // flags of my positions as a bit mask (bits past the chunk's end are zero)
     const uint32_t wi = (tile * kEmitTile + b0) >> 5;
-    uint32_t fl = wi < spc * kFlagWords ? (flagw[(uint64_t)ci * spc * kFlagWords + wi] >> (b0 & 16u)) & 0xFFFFu : 0u;
+    const uint32_t fl = wi < spc * kFlagWords ? (flagw[(uint64_t)ci * spc * kFlagWords + wi] >> (b0 & 16u)) & 0xFFFFu : 0u;
     const uint32_t cnt = (uint32_t)__builtin_popcount(fl);
-    s_scan[tid] = cnt;
+    // The results and bytes of all my positions, flagged or not, by whole-line loads issued together: nearly every
+    // line holds a flagged position, and a load per flagged position, each waited for before the next (and one more
+    // for a literal's byte), kept a thread waiting for memory several times over.
+    const uint32_t *mt = match + (t0 - base) + b0;
+    const uint8_t *dt = data + t0 + b0;
+    uint32_t mv[kPer], dw[kPer / 4];
+    if (b0 + kPer <= tn && (reinterpret_cast<uintptr_t>(mt) & 15) == 0) {
+#pragma unroll
+        for (uint32_t k = 0; k < kPer / 4; k++) {
+            const uint4 q = reinterpret_cast<const uint4 *>(mt)[k];
+            mv[4 * k] = q.x;
+            mv[4 * k + 1] = q.y;
+            mv[4 * k + 2] = q.z;
+            mv[4 * k + 3] = q.w;
+        }
+        __builtin_memcpy(dw, dt, kPer);
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; i++) mv[i] = b0 + i < tn ? mt[i] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer / 4; k++) {
+            dw[k] = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++)
+                if (b0 + 4 * k + i < tn) dw[k] |= (uint32_t)dt[4 * k + i] << (8 * i);
+        }
+    }
+    // where my units go: a scan inside every wave, then over the wave totals
+    uint32_t incl = cnt;
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off);
+        if ((tid & 63u) >= off) incl += up;
+    }
+    if ((tid & 63u) == 63u) s_wave[tid >> 6] = incl;
     __syncthreads();
-    for (uint32_t off = 1; off < kEmitThreads; off <<= 1) {
-        const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kEmitThreads / 64; w++) {
+        const uint32_t t = s_wave[w];
+        before += w < (tid >> 6) ? t : 0u;
+        total += t;
     }
     // the units of the tile are collected in LDS and leave in one coalesced copy
-    uint32_t o = s_scan[tid] - cnt;
-    const uint32_t *mt = match + (t0 - base);
-    while (fl) {
-        const uint32_t i = (uint32_t)__builtin_ctz(fl);
-        fl &= fl - 1;
-        const uint32_t r = b0 + i;
-        uint32_t mv = mt[r];
-        if (mv == kUnvisited) {  // the parse stands where no walker searched: the caller redoes the call
+    uint32_t o = before + incl - cnt;
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; i++) {
+        if (!((fl >> i) & 1u)) continue;
+        uint32_t m = mv[i];
+        if (m == kUnvisited) {  // the parse stands where no walker searched: the caller redoes the call
             atomicOr(status, 4u);
-            mv = 0;
+            m = 0;
         }
         uint32_t tok;
-        if (mv) {
-            const uint32_t len = mv >> 16, dist = mv & 0xFFFFu;
+        if (m) {
+            const uint32_t len = m >> 16, dist = m & 0xFFFFu;
             tok = ZG_TOK_MARKER | (len << 16) | dist;
             atomicAdd(&s_hist[257u + length_code_index(len)], 1u);
             atomicAdd(&s_hist[kDOff + dist_code(dist)], 1u);
         } else {
-            tok = data[t0 + r];
+            tok = (dw[i >> 2] >> ((i & 3u) * 8u)) & 0xFFu;
             atomicAdd(&s_hist[tok], 1u);
         }
         s_tok[o++] = tok;
     }
     __syncthreads();
-    const uint32_t total = s_scan[kEmitThreads - 1];
     uint32_t *tok_out = tokens + (cs - tok_base) + tile_off[(uint64_t)ci * tpc + tile];
     for (uint32_t i = tid; i < total; i += kEmitThreads) tok_out[i] = s_tok[i];
     for (uint32_t i = tid; i < kTabStride; i += kEmitThreads)
