@@ -387,7 +387,8 @@ def test_raw_large(za, z):
     assert sysz.decompress(got) == data
 
 
-@pytest.mark.parametrize("world,total,chunk", [(2, 300_000, 65536), (3, 200_000, 16384), (4, 4 << 20, 1 << 20)])
+@pytest.mark.parametrize("world,total,chunk", [(2, 300_000, 65536), (3, 200_000, 16384), (4, 4 << 20, 1 << 20),
+                                               (3, 100_000, 65536)])  # the last: two chunks, the first rank without input
 def test_shard_api_assembles_the_single_gpu_stream(za, z, world, total, chunk):
     """zg_shard_begin / zg_shard_finish for every rank's run of chunks (run one after the other on this GPU),
     assembled with the host logic the multi-GPU bench uses, give the stream of a single compress call."""
@@ -421,7 +422,8 @@ def test_shard_api_assembles_the_single_gpu_stream(za, z, world, total, chunk):
 
 
 @pytest.mark.parametrize("world,total,chunk,batch", [(3, (6 << 20) + 4321, 1 << 16, 1 << 19), (2, 300_000, 16384, 16384),
-                                                     (4, 3 << 20, 1 << 18, 1 << 20), (1, 1_000_000, 1 << 17, 1 << 18)])
+                                                     (4, 3 << 20, 1 << 18, 1 << 20), (1, 1_000_000, 1 << 17, 1 << 18),
+                                                     (3, 100_000, 65536, 65536), (2, 0, 65536, 65536)])  # ranks without input
 def test_shard_pieces_assemble_the_single_gpu_stream(za, z, world, total, chunk, batch):
     """zg_shard_open / zg_shard_next for every rank's run (one after the other on this GPU), pass by pass; every
     piece is copied away the moment it is reported, as an exchange that runs beside the kernels would, and the
@@ -430,7 +432,7 @@ def test_shard_pieces_assemble_the_single_gpu_stream(za, z, world, total, chunk,
     import torch
     from zlib_amd import sharding
     data = za.corpus("mixed" if total > (1 << 20) else "text", total, seed=31)
-    whole = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    whole = torch.frombuffer(bytearray(data) or bytearray(1), dtype=torch.uint8).cuda()
     plan = sharding.plan_shards(total, chunk, world)
     bound = lambda n: za.compress_bound(n, za.Strategy.Dynamic, chunk_bytes=chunk)
     stages, infos, n_pieces, ctxs = [], [], [], []
@@ -450,14 +452,15 @@ def test_shard_pieces_assemble_the_single_gpu_stream(za, z, world, total, chunk,
             at, k = at + nb, k + 1
             if last:
                 break
-        assert k == -(-max(1, -(-n // chunk)) // max(1, batch // chunk))
+        n_blocks = -(-n // chunk) or (1 if r == world - 1 else 0)  # a run without bytes adds nothing unless it is the last
+        assert k == max(1, -(-n_blocks // max(1, batch // chunk)))
         torch.cuda.synchronize()
         assert torch.equal(stage[:at], packed[:at]), "a piece changed after it had been reported"
         n_pieces.append(k)
         stages.append(stage)
         infos.append((bits, ad, n))
         blocks = za.last_block_offsets(ctx=ctx)
-        assert len(blocks) == max(1, -(-n // chunk)) and blocks[0] == 0 and all(a < b for a, b in zip(blocks, blocks[1:]))
+        assert len(blocks) == n_blocks and blocks[:1] in ([], [0]) and all(a < b for a, b in zip(blocks, blocks[1:]))
         with pytest.raises(za.ZgError):
             eng.next()  # the run has ended
     bases, end_bit, adler = sharding.stream_layout(infos)

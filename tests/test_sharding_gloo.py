@@ -28,7 +28,7 @@ class OracleEngine:
         self.blocks = []
 
     def begin(self, last_rank):
-        nchunks = max(1, -(-self.n // self.chunk))
+        nchunks = -(-self.n // self.chunk) or (1 if last_rank else 0)  # a run without bytes adds nothing unless it is the last
         c0 = self.start // self.chunk
         self.blocks = []
         for c in range(nchunks):
@@ -59,7 +59,7 @@ class OraclePieceEngine:
         self.packed = torch.zeros(n * 2 + 4096, dtype=torch.uint8)
 
     def open(self, last_rank):
-        nchunks = max(1, -(-self.n // self.chunk))
+        nchunks = -(-self.n // self.chunk) or (1 if last_rank else 0)  # a run without bytes adds nothing unless it is the last
         c0 = self.start // self.chunk
         self.blocks = []
         for c in range(nchunks):
@@ -69,14 +69,15 @@ class OraclePieceEngine:
         self.packed.fill_(0xEE)  # stale bytes of an earlier call
 
     def next(self):
-        assert self.at < len(self.blocks)
+        assert self.at < max(1, len(self.blocks))
         for blk, bits in self.blocks[self.at:self.at + self.pass_chunks]:
             self.acc |= int.from_bytes(blk, "little") << self.pos
             self.pos += bits
         self.at = min(len(self.blocks), self.at + self.pass_chunks)
         last = self.at == len(self.blocks)
         raw = self.acc.to_bytes((self.pos + 7) // 8, "little")  # the unfinished byte is in the buffer, not in the piece
-        self.packed[self.reported:len(raw)] = torch.frombuffer(bytearray(raw[self.reported:]), dtype=torch.uint8)
+        if len(raw) > self.reported:
+            self.packed[self.reported:len(raw)] = torch.frombuffer(bytearray(raw[self.reported:]), dtype=torch.uint8)
         done = len(raw) if last else self.pos // 8
         off, self.reported = self.reported, done
         ad = zref.adler32(self.data[self.start:self.start + self.n]) if last else None
@@ -91,7 +92,8 @@ class OraclePieceEngine:
         lo, ph = base_bit // 8, base_bit % 8
         keep = int(final[lo]) & ((1 << ph) - 1) if ph else 0
         raw = (keep | (run << ph)).to_bytes((ph + n_bits + 7) // 8, "little")
-        final[lo:lo + len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        if raw:
+            final[lo:lo + len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
 
     @staticmethod
     def seal(final, end_bit, adler):
@@ -132,6 +134,8 @@ def _piece_worker(rank, world, port, total, chunk, pass_chunks, q, piece=None):
     (3, 100_000, 8192, 1, None),    # a pass per chunk: 4 or 5 passes per rank
     (3, 100_000, 8192, 3, 1000),    # pieces travel in several point-to-point operations
     (3, 20_000, 8192, 1, None),     # 3 chunks over 3 ranks, the last one short
+    (3, 10_000, 8192, 2, None),     # 2 chunks over 3 ranks: the first rank has no input and adds nothing
+    (2, 0, 8192, 2, None),          # no input at all: the last rank writes the one empty block
 ])
 def test_overlapped_assembly_equals_single_stream(world, total, chunk, pass_chunks, piece):
     """The exchange that runs beside the kernels: per pass one all_gather of piece sizes and one send of the bytes
@@ -194,7 +198,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,total,chunk,piece", [(2, 150_000, 16384, None), (2, 65536, 32768, None),
-                                                     (3, 100_000, 8192, None), (3, 100_000, 8192, 1000)])
+                                                     (3, 100_000, 8192, None), (3, 100_000, 8192, 1000),
+                                                     (3, 10_000, 8192, None)])  # the last: a rank without input
 def test_sharded_assembly_equals_single_stream(world, total, chunk, piece):
     _lib.lib()  # adler32_combine comes from the product library (host function)
     ctx = mp.get_context("spawn")

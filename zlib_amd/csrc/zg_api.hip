@@ -1253,9 +1253,11 @@ int shard_begin_locked(zg_ctx *c, const void *d_in, size_t halo, size_t n, int s
     g.first = halo;
     g.end = halo + n;
     g.chunk_bytes = plan.chunk_bytes;
-    g.n_chunks = n == 0 ? 1u : (uint32_t)((n + plan.chunk_bytes - 1) / plan.chunk_bytes);
+    // a run without bytes adds nothing to the stream -- unless it is the last: the stream of an empty input is one
+    // empty final block
+    g.n_chunks = n == 0 ? (last_rank ? 1u : 0u) : (uint32_t)((n + plan.chunk_bytes - 1) / plan.chunk_bytes);
     const uint32_t max_tiles = max_tiles_for(plan.chunk_bytes);
-    const size_t bc = std::min<size_t>(plan.batch_chunks, g.n_chunks);
+    const size_t bc = std::max<size_t>(1, std::min<size_t>(plan.batch_chunks, g.n_chunks));
     const size_t bound = (zg_compress_bound(n, strategy, opts) + 3) & ~(size_t)3;
     const MatchParams mp{kMaxWindow, 3, 258};
     // The rank's blocks are packed from bit 0 of a buffer of its own, batch by batch as in a whole-stream call;
@@ -1368,12 +1370,15 @@ int shard_queue_batch(zg_ctx *c) {
     const uint32_t c1 = (uint32_t)std::min<uint64_t>(r.g.n_chunks, (uint64_t)c0 + r.bc);
     const int64_t final_chunk = (r.last_rank && c1 == r.g.n_chunks) ? (int64_t)(c1 - c0 - 1) : -1;
     const MatchParams mp{kMaxWindow, 3, 258};
-    int rc = run_front(c, r.g, c0, c1, mp, r.strategy, final_chunk, true);
-    if (rc) return rc;
-    rc = run_back(c, r.g, c0, c1, r.max_tiles, r.packed, r.cap_bits);
-    if (rc) return rc;
-    rc = keep_block_offsets(c, c0, c1);
-    if (rc) return rc;
+    int rc = ZG_OK;
+    if (c1 > c0) {
+        rc = run_front(c, r.g, c0, c1, mp, r.strategy, final_chunk, true);
+        if (rc) return rc;
+        rc = run_back(c, r.g, c0, c1, r.max_tiles, r.packed, r.cap_bits);
+        if (rc) return rc;
+        rc = keep_block_offsets(c, c0, c1);
+        if (rc) return rc;
+    }
     if (c1 == r.g.n_chunks) {  // the last batch: the rank's Adler-32 rides behind it
         rc = run_adler(c, r.g.data + r.halo, r.n);
         if (rc) return rc;
@@ -1437,12 +1442,13 @@ int zg_shard_open(zg_ctx *ctx, const void *d_in, size_t halo, size_t n, int stra
     r.g.first = halo;
     r.g.end = halo + n;
     r.g.chunk_bytes = plan.chunk_bytes;
-    r.g.n_chunks = n == 0 ? 1u : (uint32_t)((n + plan.chunk_bytes - 1) / plan.chunk_bytes);
+    // (a run without bytes adds nothing to the stream unless it is the last: see zg_shard_begin)
+    r.g.n_chunks = n == 0 ? (last_rank ? 1u : 0u) : (uint32_t)((n + plan.chunk_bytes - 1) / plan.chunk_bytes);
     r.strategy = strategy;
     r.last_rank = last_rank;
     r.max_tiles = max_tiles_for(plan.chunk_bytes);
-    r.bc = (uint32_t)std::min<size_t>(plan.batch_chunks, r.g.n_chunks);
-    r.n_batches = (r.g.n_chunks + r.bc - 1) / r.bc;
+    r.bc = (uint32_t)std::max<size_t>(1, std::min<size_t>(plan.batch_chunks, r.g.n_chunks));
+    r.n_batches = std::max<uint32_t>(1, (r.g.n_chunks + r.bc - 1) / r.bc);  // a run of no chunks: one pass that gives nothing
     r.queued = r.reported = 0;
     r.packed = static_cast<uint32_t *>(d_packed);
     r.cap_bits = (uint64_t)(packed_cap & ~(size_t)3) * 8;
