@@ -185,7 +185,9 @@ int zg_decompress_batch_device(zg_ctx *ctx, const void *d_in, const uint64_t *d_
  * chunk_bytes must be 32768 or more (ZG_ERR_UNSUPPORTED otherwise) and the blocks
  * Dynamic or Fixed.  d_stream / d_out are device pointers; d_out needs n bytes.
  * A stream that does not fit the description, or is corrupt, or fails its
- * Adler-32: ZG_ERR_DATA (zg_last_error says what and in which block). */
+ * Adler-32: ZG_ERR_DATA (zg_last_error says what and in which block).  Scratch:
+ * 6 bytes per byte of output for at most 4 GiB of output at a time (tokens and
+ * 16-bit units of the blocks in flight), and 32 KiB per block of the stream. */
 int zg_decompress_blocks_device(zg_ctx *ctx, const void *d_stream, size_t stream_bytes, const uint64_t *bit_offsets,
                                 size_t n_blocks, size_t chunk_bytes, void *d_out, size_t n);
 
@@ -202,9 +204,7 @@ int zg_decompress_blocks_device(zg_ctx *ctx, const void *d_stream, size_t stream
  * the header; byte 0 of d_out is then byte 0 of the stream), last_rank sets BFINAL on its last block
  * and appends the Adler-32 passed in `adler` (combined by the caller with
  * zg_adler32_combine).  A rank with n == 0 adds no block (total_bits 0) -- unless
- * it is the last rank: the stream of an empty input is one empty final block.
- * Scratch of zg_decompress_blocks_device above: for a pass of 4 GiB of output,
- * 4 bytes of tokens and 2 bytes of units per output byte, and 32 KiB per block. */
+ * it is the last rank: the stream of an empty input is one empty final block. */
 typedef struct zg_shard_info {
     uint64_t total_bits; /* bits of all blocks of this rank (no zlib header/trailer) */
     uint32_t adler;      /* Adler-32 of this rank's n bytes taken alone             */
