@@ -853,10 +853,21 @@ __global__ __launch_bounds__(kEncThreads) void k_tile_bits(uint32_t max_tiles, c
     if (tid < 32) s_d[tid] = tab[(uint64_t)ci * kTabStride + kDOff + tid];
     __syncthreads();
     const uint32_t *tok = tokens + (first + (uint64_t)(c0 + ci) * chunk_bytes - tok_base);
-    uint32_t sum = 0;
-    for (uint32_t k = 0; k < kEncTile / kEncThreads; k++) {
+    // all of a thread's units are loaded before the first is looked at (a load inside the loop was waited for on
+    // every turn); indices past the block's end are clamped and their units dropped
+    constexpr uint32_t kPer = kEncTile / kEncThreads;
+    uint32_t t[kPer];
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) {
         const uint32_t u = tile * kEncTile + k * kEncThreads + tid;
-        if (u < nunits) sum += code_unit(u + 1 == nunits ? kTokEob : tok[u], s_ll, s_d).n;
+        t[k] = tok[u + 1 < nunits ? u : (nunits >= 2u ? nunits - 2u : 0u)];  // (the last unit is the end of block: not in memory)
+    }
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) {
+        const uint32_t u = tile * kEncTile + k * kEncThreads + tid;
+        const uint32_t n = code_unit(u + 1 < nunits ? t[k] : kTokEob, s_ll, s_d).n;  // (past the end: any valid unit)
+        sum += u < nunits ? n : 0u;
     }
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
     if ((tid & 63) == 0) s_red[tid >> 6] = sum;
@@ -1064,7 +1075,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode(uint32_t max_tiles, cons
     __shared__ uint32_t s_ll[kHuffMaxSyms];
     __shared__ uint32_t s_d[32];
     __shared__ uint32_t s_img[kEncWords];
-    __shared__ uint32_t s_scan[kEncThreads];
+    __shared__ uint32_t s_scan[kEncThreads / 64];
 
     const uint32_t ci = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const uint32_t nunits = ntok[ci] + 1u;
@@ -1101,28 +1112,40 @@ __global__ __launch_bounds__(kEncThreads) void k_encode(uint32_t max_tiles, cons
     Coded cu[kPer];
     uint32_t sum = 0;
     const uint32_t u0 = tile * kEncTile + tid * kPer;
+    // all of a thread's units are loaded before the first is looked at (see k_tile_bits)
+    uint32_t tk[kPer];
 #pragma unroll
     for (uint32_t k = 0; k < kPer; k++) {
         const uint32_t u = u0 + k;
-        if (u < nunits) {
-            cu[k] = code_unit(u + 1 == nunits ? kTokEob : tok[u], s_ll, s_d);
-        } else {
+        tk[k] = tok[u + 1 < nunits ? u : (nunits >= 2u ? nunits - 2u : 0u)];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) {
+        const uint32_t u = u0 + k;
+        cu[k] = code_unit(u + 1 < nunits ? tk[k] : kTokEob, s_ll, s_d);  // (past the end: any valid unit, dropped below)
+        if (u >= nunits) {
             cu[k].bits = 0;
             cu[k].n = 0;
         }
         sum += cu[k].n;
     }
-    s_scan[tid] = sum;
-    __syncthreads();
-    for (uint32_t off = 1; off < kEncThreads; off <<= 1) {
-        const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
+    // where a thread's bits go: a scan inside every wave, then over the wave totals
+    uint32_t incl = sum;
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off);
+        if ((tid & 63u) >= off) incl += up;
     }
-    const uint32_t total = s_scan[kEncThreads - 1];
+    if ((tid & 63u) == 63u) s_scan[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kEncThreads / 64; w++) {
+        const uint32_t v = s_scan[w];
+        before += w < (tid >> 6) ? v : 0u;
+        total += v;
+    }
     const uint32_t img_sh = (uint32_t)(tile_bit & 31u);  // bit position of the tile start inside image word 0
-    uint32_t pos = img_sh + s_scan[tid] - sum;
+    uint32_t pos = img_sh + before + incl - sum;
 #pragma unroll
     for (uint32_t k = 0; k < kPer; k++) {
         const uint32_t n = cu[k].n;
