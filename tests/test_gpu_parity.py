@@ -571,6 +571,49 @@ def test_record_batch_large_records_and_device_entry(za, z):
     assert sysz.decompress(out[off[n - 1]:off[n]]) == data[(n - 1) * stride:]
 
 
+@pytest.mark.parametrize("strategy", ["Dynamic", "Fixed"])
+def test_record_batch_into_a_dirty_buffer(za, z, strategy):
+    """The record path clears only the words its bit packer ORs into, not the output: every byte of every stream must
+    come out right over whatever the buffer held -- two batches of different records into the same buffer of 0xEE
+    bytes, the second one shorter; records of odd lengths so that streams begin at every byte phase; records of 4 KiB
+    over more than one pass."""
+    import torch
+    st, zs = getattr(za.Strategy, strategy), (z.DYNAMIC if strategy == "Dynamic" else z.FIXED)
+    rng = random.Random(5)
+    stride = 1024  # (slots are multiples of 1 KiB; the records in them are not)
+    for n, seed in ((700, 1), (300, 2)):
+        recs = [za.corpus("records" if i % 3 else "text", rng.randint(0, stride), seed=seed, offset=997 * i) for i in range(n)]
+        slots = b"".join(r + bytes(stride - len(r)) for r in recs)
+        d_in = torch.frombuffer(bytearray(slots), dtype=torch.uint8).cuda()
+        d_len = torch.tensor([len(r) for r in recs], dtype=torch.int32).cuda()
+        cap = za.compress_batch_bound(stride, 700, st)
+        if n == 700:
+            d_out = torch.full((cap,), 0xEE, dtype=torch.uint8, device="cuda")
+            d_off = torch.zeros(701, dtype=torch.int64, device="cuda")
+        total = za.compress_batch_device(d_in.data_ptr(), stride, d_len.data_ptr(), n, d_out.data_ptr(), cap, d_off.data_ptr(), st)
+        off = d_off.cpu().tolist()
+        out = d_out[:total].cpu().numpy().tobytes()
+        assert off[0] == 0 and off[n] == total
+        for i, r in enumerate(recs):
+            _same(out[off[i]:off[i + 1]], z.compress_chunked(r, zs, 1 << 20, fast=True), (strategy, n, i, len(r)))
+    n, stride = 40_000, 4096  # 160 MB: two passes over the scratch buffers
+    d_in = torch.empty(n * stride, dtype=torch.uint8, device="cuda")
+    host = torch.empty(n * stride, dtype=torch.uint8)
+    za.corpus_into("records", host.data_ptr(), n * stride, seed=9)
+    d_in.copy_(host)
+    cap = za.compress_batch_bound(stride, n, st)
+    d_out = torch.full((cap,), 0xEE, dtype=torch.uint8, device="cuda")
+    d_off = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    total = za.compress_batch_device(d_in.data_ptr(), stride, 0, n, d_out.data_ptr(), cap, d_off.data_ptr(), st)
+    off = d_off.cpu().tolist()
+    out = d_out[:total].cpu().numpy().tobytes()
+    data = host.numpy().tobytes()
+    for i in list(range(0, n, 211)) + [32767, 32768, 32769, n - 1]:  # the pass seam is at record 32768
+        assert sysz.decompress(out[off[i]:off[i + 1]]) == data[i * stride:(i + 1) * stride], i
+    for i in (0, 32767, 32768, n - 1):
+        _same(out[off[i]:off[i + 1]], z.compress_chunked(data[i * stride:(i + 1) * stride], zs, 1 << 20, fast=True), i)
+
+
 def test_one_chunk_of_the_accepted_maximum(za):
     """256 MiB of incompressible bytes as ONE block: more than 2^31 payload bits, the largest the 32-bit tile
     offsets inside a block have to carry."""

@@ -368,7 +368,7 @@ int run_back(zg_ctx *c, const ChunkGrid &g, uint32_t c0, uint32_t c1, uint32_t m
     // the words k_encode ORs into; the rest of the output needs no clearing
     LAUNCH(K_OFFSETS, launch_zero_seams(c1 - c0, max_tiles, c->ntok.as<uint32_t>(), c->hdr_bits.as<uint32_t>(),
                                         c->tile_bits.as<uint32_t>(), c->bit_off.as<uint64_t>(),
-                                        c->block_bits.as<uint64_t>(), out, out_cap_bits, c->stream));
+                                        c->block_bits.as<uint64_t>(), out, out_cap_bits, false, c->stream));
     LAUNCH(K_ENCODE, launch_encode(c1 - c0, max_tiles, c->tokens.as<uint32_t>(), g, c0, bs, c->ntok.as<uint32_t>(),
                                    c->tab.as<uint32_t>(), c->hdr.as<uint32_t>(), c->hdr_bits.as<uint32_t>(),
                                    c->tile_bits.as<uint32_t>(), c->bit_off.as<uint64_t>(), out, out_cap_bits,
@@ -759,7 +759,6 @@ int compress_batch_once(zg_ctx *c, const uint8_t *d_in, size_t stride, const uin
     rc = ensure_chunk_meta(c, bc, max_tiles);
     if (rc) return rc;
     HIPCHK(c->adler_part.ensure(bc * 2 * sizeof(uint32_t)));
-    LAUNCH(K_MISC, hipMemsetAsync(d_out, 0, zg_compress_batch_bound(stride, n_records, strategy), c->stream));
     const MatchParams mp{kMaxWindow, 3, 258};  // get_zlib_compressor, src/compress.rs:451-456
     for (uint32_t c0 = 0; c0 < g.n_chunks; c0 += (uint32_t)bc) {
         const uint32_t c1 = (uint32_t)std::min<uint64_t>(g.n_chunks, (uint64_t)c0 + bc);
@@ -773,6 +772,11 @@ int compress_batch_once(zg_ctx *c, const uint8_t *d_in, size_t stride, const uin
                                            c->stream));
         LAUNCH(K_OFFSETS, launch_batch_offsets(c1 - c0, c->block_bits.as<uint64_t>(), c->bit_off.as<uint64_t>(),
                                                &sc->carry, d_off + c0, c->stream));
+        // the words k_encode ORs into; the rest of the output needs no clearing
+        LAUNCH(K_OFFSETS, launch_zero_seams(c1 - c0, max_tiles, c->ntok.as<uint32_t>(), c->hdr_bits.as<uint32_t>(),
+                                            c->tile_bits.as<uint32_t>(), c->bit_off.as<uint64_t>(),
+                                            c->block_bits.as<uint64_t>(), reinterpret_cast<uint32_t *>(d_out),
+                                            (uint64_t)out_cap * 8, true, c->stream));
         LAUNCH(K_ENCODE, launch_encode(c1 - c0, max_tiles, c->tokens.as<uint32_t>(), g, c0, bs, c->ntok.as<uint32_t>(),
                                        c->tab.as<uint32_t>(), c->hdr.as<uint32_t>(), c->hdr_bits.as<uint32_t>(),
                                        c->tile_bits.as<uint32_t>(), c->bit_off.as<uint64_t>(),

@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(256) void k_zero_seams(uint32_t max_tiles, const ui
                                                      const uint32_t *__restrict__ tile_off,
                                                      const uint64_t *__restrict__ bit_off,
                                                      const uint64_t *__restrict__ block_bits, uint32_t *out,
-                                                     uint64_t out_cap_bits) {
+                                                     uint64_t out_cap_bits, uint32_t separate) {
     const uint32_t ci = blockIdx.y;
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     const uint32_t nt = (ntok[ci] + 1u + kEncTile - 1) / kEncTile;
@@ -1197,6 +1197,14 @@ __global__ __launch_bounds__(256) void k_zero_seams(uint32_t max_tiles, const ui
     // short block ends in it
     const uint64_t keep = (bit_off[0] & 31u) ? bit_off[0] >> 5 : ~0ull;
     const uint32_t hb = hdr_bits[ci];
+    // separate != 0: every block is a stream of its own between two header bytes and four trailer bytes (written
+    // byte by byte afterwards).  The word a block begins in the middle of is then no tile's end word: the bytes from
+    // the block's first to the end of that word are cleared one by one -- the bytes below them may hold the stream
+    // before, of this batch or of the last one.
+    if (separate && blockIdx.x == 0 && threadIdx.x == 0 && (blk_bit & 31u)) {
+        uint8_t *ob = reinterpret_cast<uint8_t *>(out);
+        for (uint64_t b = blk_bit >> 3; b < ((blk_bit >> 5) + 1) * 4 && b * 8 < out_cap_bits; b++) ob[b] = 0;
+    }
     if (blockIdx.x == 0) {
         const uint64_t w_hi = (blk_bit + hb) >> 5;
         for (uint64_t w = ((blk_bit + 31) >> 5) + threadIdx.x; w <= w_hi && w <= last_word; w += 256)
@@ -1216,10 +1224,10 @@ __global__ __launch_bounds__(256) void k_zero_seams(uint32_t max_tiles, const ui
 
 hipError_t launch_zero_seams(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *ntok, const uint32_t *hdr_bits,
                              const uint32_t *tile_off, const uint64_t *bit_off, const uint64_t *block_bits,
-                             uint32_t *out, uint64_t out_cap_bits, hipStream_t s) {
+                             uint32_t *out, uint64_t out_cap_bits, bool separate, hipStream_t s) {
     if (!n_chunks) return hipSuccess;
     hipLaunchKernelGGL(k_zero_seams, dim3((max_tiles + 255) / 256, n_chunks), dim3(256), 0, s, max_tiles, ntok, hdr_bits,
-                       tile_off, bit_off, block_bits, out, out_cap_bits);
+                       tile_off, bit_off, block_bits, out, out_cap_bits, separate ? 1u : 0u);
     return hipGetLastError();
 }
 

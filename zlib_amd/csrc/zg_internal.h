@@ -160,7 +160,7 @@ hipError_t launch_offsets(uint32_t n_chunks, uint32_t max_tiles, const uint32_t 
                           const uint64_t *block_bits, uint64_t *bit_off, uint64_t *carry, hipStream_t s);
 hipError_t launch_zero_seams(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *ntok, const uint32_t *hdr_bits,
                              const uint32_t *tile_off, const uint64_t *bit_off, const uint64_t *block_bits,
-                             uint32_t *out, uint64_t out_cap_bits, hipStream_t s);
+                             uint32_t *out, uint64_t out_cap_bits, bool separate, hipStream_t s);
 hipError_t launch_encode(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *tokens, const ChunkGrid &g,
                          uint32_t c0, uint64_t tok_base, const uint32_t *ntok, const uint32_t *tab,
                          const uint32_t *hdr, const uint32_t *hdr_bits, const uint32_t *tile_off,
