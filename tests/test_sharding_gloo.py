@@ -54,9 +54,10 @@ class OraclePieceEngine:
     """What zg_shard_open / _next / _merge / _seal do on a GPU, restated with the oracle's blocks and Python integers:
     a pass is `pass_chunks` blocks; after it the buffer holds all bits so far, of which the complete bytes are final."""
 
-    def __init__(self, data, start, n, chunk, pass_chunks):
+    def __init__(self, data, start, n, chunk, pass_chunks, fail_first_run=False):
         self.data, self.start, self.n, self.chunk, self.pass_chunks = data, start, n, chunk, pass_chunks
         self.packed = torch.zeros(n * 2 + 4096, dtype=torch.uint8)
+        self.fail = fail_first_run  # the first run ends as a run whose device-side self-check failed
 
     def open(self, last_rank):
         nchunks = -(-self.n // self.chunk) or (1 if last_rank else 0)  # a run without bytes adds nothing unless it is the last
@@ -75,6 +76,9 @@ class OraclePieceEngine:
             self.pos += bits
         self.at = min(len(self.blocks), self.at + self.pass_chunks)
         last = self.at == len(self.blocks)
+        if last and self.fail:
+            self.fail = False
+            raise _lib.ZgError(_lib.ERR_INTERNAL, "self-check")
         raw = self.acc.to_bytes((self.pos + 7) // 8, "little")  # the unfinished byte is in the buffer, not in the piece
         if len(raw) > self.reported:
             self.packed[self.reported:len(raw)] = torch.frombuffer(bytearray(raw[self.reported:]), dtype=torch.uint8)
@@ -102,7 +106,7 @@ class OraclePieceEngine:
         return at + 4
 
 
-def _piece_worker(rank, world, port, total, chunk, pass_chunks, q, piece=None):
+def _piece_worker(rank, world, port, total, chunk, pass_chunks, q, piece=None, fail_rank=-1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if piece:
@@ -112,7 +116,7 @@ def _piece_worker(rank, world, port, total, chunk, pass_chunks, q, piece=None):
         data = _corpus(total)
         plan = sharding.plan_shards(total, chunk, world)
         start, n, _halo = plan[rank]
-        eng = OraclePieceEngine(data, start, n, chunk, pass_chunks)
+        eng = OraclePieceEngine(data, start, n, chunk, pass_chunks, fail_first_run=rank == fail_rank)
         final = stages = None
         if rank == 0:
             final = torch.full((total * 2 + 4096,), 0xEE, dtype=torch.uint8)
@@ -155,6 +159,27 @@ def test_overlapped_assembly_equals_single_stream(world, total, chunk, pass_chun
     data = _corpus(total)
     assert stream == zref.compress_chunked(data, zref.DYNAMIC, chunk, fast=True)
     assert sysz.decompress(stream) == data
+
+
+@pytest.mark.parametrize("fail_rank", [0, 1, 2])
+def test_overlapped_assembly_starts_over_when_a_rank_fails_its_self_check(fail_rank):
+    """ZG_ERR_INTERNAL from a rank's last zg_shard_next (the library has switched to its conservative kernels): the
+    rank reports it with its last row, every rank drops what it has and runs again; rank 1 has fewer passes than the
+    others, so ranks that are done and ranks in the middle of their run are both among those that start over."""
+    _lib.lib()
+    world, total, chunk, pass_chunks = 3, 100_000, 8192, 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_piece_worker, args=(r, world, port, total, chunk, pass_chunks, q, None, fail_rank))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    stream = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert stream == zref.compress_chunked(_corpus(total), zref.DYNAMIC, chunk, fast=True)
 
 
 def test_overlapped_assembly_with_one_rank():

@@ -32,7 +32,7 @@ from __future__ import annotations
 
 from typing import List, Tuple
 
-from . import api
+from . import _lib, api
 
 ADLER_INIT = 1
 P2P_PIECE = 1 << 30  # bytes per point-to-point operation (some backends count a message in 32 bits)
@@ -200,53 +200,69 @@ def compress_sharded_overlapped(engine, dist, torch, rank: int, world: int, devi
     meta = "cpu" if staged else device
     local = scratch.setdefault("piece", torch.zeros(5, dtype=torch.int64, device=meta))
     gathered = scratch.setdefault("pieces", torch.zeros(5 * world, dtype=torch.int64, device=meta))
-    engine.open(last_rank)
-    done, got, totals = [False] * world, [0] * world, [None] * world
-    mine = None  # (bits, adler) once this rank's last piece is out
-    while not all(done):
-        if mine is None:
-            off, nb, bits, last, ad = engine.next()  # queues the next pass's kernels, then waits for the oldest pass
-            row = [nb, bits, ad if last else 0, 1 if last else 0, engine.n]
-            if last:
-                mine = (bits, ad)
+    # A run can end with the library's device-side self-check failed (ZG_ERR_INTERNAL: the context has then switched to
+    # its conservative kernels).  The rank says so in its last row, and every rank starts over, once.
+    for attempt in range(2):
+        engine.open(last_rank)
+        done, got, totals = [False] * world, [0] * world, [None] * world
+        mine = None  # (bits, adler) once this rank's last piece is out
+        failed = False
+        while not all(done):
+            if mine is None:
+                try:
+                    off, nb, bits, last, ad = engine.next()  # queues the next pass's kernels, then waits for the oldest pass
+                except api.ZgError as e:
+                    if e.code != _lib.ERR_INTERNAL or attempt:
+                        raise
+                    off, nb, bits, last, ad = 0, 0, 0, True, 0
+                    failed = True
+                row = [nb, bits, ad if last else 0, (2 if failed else 1) if last else 0, engine.n]
+                if last:
+                    mine = (bits, ad)
+            else:
+                off, nb, row = 0, 0, [0, mine[0], mine[1], 2 if failed else 1, engine.n]
+            local.copy_(torch.tensor(row, dtype=torch.int64))
+            try:
+                dist.all_gather_into_tensor(gathered, local)
+            except (RuntimeError, NotImplementedError):
+                parts = [torch.zeros_like(local) for _ in range(world)]
+                dist.all_gather(parts, local)
+                gathered.copy_(torch.cat(parts))
+            rows = gathered.view(world, 5).tolist()
+            ops, landed = [], []
+            if first:
+                for r in range(1, world):
+                    nbr = int(rows[r][0])
+                    if stages[r].numel() < got[r] + nbr + 8:
+                        raise ValueError(f"staging buffer of rank {r} is too small")
+                    for lo in range(0, nbr, P2P_PIECE):
+                        view = stages[r].narrow(0, got[r] + lo, min(nbr - lo, P2P_PIECE))
+                        if staged:
+                            host = torch.empty(view.numel(), dtype=torch.uint8)
+                            landed.append((view, host))
+                            view = host
+                        ops.append(dist.P2POp(dist.irecv, view, r))
+                    got[r] += nbr
+            elif nb:
+                src = packed.narrow(0, off, nb)
+                if staged:
+                    src = src.cpu()
+                for lo in range(0, nb, P2P_PIECE):
+                    ops.append(dist.P2POp(dist.isend, src.narrow(0, lo, min(nb - lo, P2P_PIECE)), 0))
+            if ops:  # the GPU has the next pass queued: it computes while these bytes travel
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            for view, host in landed:
+                view.copy_(host)
+            for r in range(world):
+                if rows[r][3]:
+                    done[r], totals[r] = True, (int(rows[r][1]), int(rows[r][2]), int(rows[r][4]))
+            if any(int(rows[r][3]) == 2 for r in range(world)):
+                break  # some rank has to start over: so does everybody (runs still open are dropped by the next open)
         else:
-            off, nb, row = 0, 0, [0, mine[0], mine[1], 1, engine.n]
-        local.copy_(torch.tensor(row, dtype=torch.int64))
-        try:
-            dist.all_gather_into_tensor(gathered, local)
-        except (RuntimeError, NotImplementedError):
-            parts = [torch.zeros_like(local) for _ in range(world)]
-            dist.all_gather(parts, local)
-            gathered.copy_(torch.cat(parts))
-        rows = gathered.view(world, 5).tolist()
-        ops, landed = [], []
-        if first:
-            for r in range(1, world):
-                nbr = int(rows[r][0])
-                if stages[r].numel() < got[r] + nbr + 8:
-                    raise ValueError(f"staging buffer of rank {r} is too small")
-                for lo in range(0, nbr, P2P_PIECE):
-                    view = stages[r].narrow(0, got[r] + lo, min(nbr - lo, P2P_PIECE))
-                    if staged:
-                        host = torch.empty(view.numel(), dtype=torch.uint8)
-                        landed.append((view, host))
-                        view = host
-                    ops.append(dist.P2POp(dist.irecv, view, r))
-                got[r] += nbr
-        elif nb:
-            src = packed.narrow(0, off, nb)
-            if staged:
-                src = src.cpu()
-            for lo in range(0, nb, P2P_PIECE):
-                ops.append(dist.P2POp(dist.isend, src.narrow(0, lo, min(nb - lo, P2P_PIECE)), 0))
-        if ops:  # the GPU has the next pass queued: it computes while these bytes travel
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        for view, host in landed:
-            view.copy_(host)
-        for r in range(world):
-            if rows[r][3]:
-                done[r], totals[r] = True, (int(rows[r][1]), int(rows[r][2]), int(rows[r][4]))
+            break  # every rank's last piece is in
+        if packed.is_cuda:
+            torch.cuda.current_stream(device).synchronize()  # nothing of this attempt is in flight when the next begins
     bases, end_bit, adler = stream_layout(totals)
     total_bytes = (end_bit + 7) // 8 + 4
     if packed.is_cuda:
