@@ -337,7 +337,8 @@ pub mod huffman {
         /// GPU; the two trees are then built from those lengths with the crate's own from_bitlen_list
         /// (src/huffman.rs:311-337).  They are canonical from the start, so `assign` + `to_canonical`, which
         /// compress_dynamic applies next (src/compress.rs:296-314), leave exactly the codes the crate arrives at
-        /// (the code LENGTHS are the crate's wherever its heap order is defined).
+        /// (the code LENGTHS are the crate's wherever its heap order is defined: equal-weight internal nodes, which
+        /// the crate takes in the order of a randomly seeded HashMap, are taken older first; the total cost is the same).
         /// Panics like check_lz77 (src/huffman.rs:817-835) on other than the zlib parameters.
         pub fn from_lz77(data: &[lz77::LZ77Unit], lz77: &lz77::LZ77Compressor) -> (Self, Self) {
             assert_eq!(lz77.window_size, ZLIB_WINDOW_SIZE, "Incompatible LZ77 window size");
