@@ -186,8 +186,9 @@ int zg_decompress_batch_device(zg_ctx *ctx, const void *d_in, const uint64_t *d_
  * Dynamic or Fixed.  d_stream / d_out are device pointers; d_out needs n bytes.
  * A stream that does not fit the description, or is corrupt, or fails its
  * Adler-32: ZG_ERR_DATA (zg_last_error says what and in which block).  Scratch:
- * 6 bytes per byte of output for at most 4 GiB of output at a time (tokens and
- * 16-bit units of the blocks in flight), and 32 KiB per block of the stream. */
+ * 6 bytes per byte of output for at most 8 GiB of output at a time (tokens and
+ * 16-bit units of the blocks in flight: two passes of 4 GiB), and 32 KiB per
+ * block of the stream. */
 int zg_decompress_blocks_device(zg_ctx *ctx, const void *d_stream, size_t stream_bytes, const uint64_t *bit_offsets,
                                 size_t n_blocks, size_t chunk_bytes, void *d_out, size_t n);
 

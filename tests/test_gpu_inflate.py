@@ -116,6 +116,23 @@ def test_all_blocks_of_a_stream_at_once(za, strategy):
         assert sysz.decompress(stream) == data
 
 
+def test_all_blocks_in_several_passes(za, monkeypatch):
+    """Streams larger than the scratch buffers take several passes, two of them in flight (the tokens of one are
+    expanded while the next is decoded); here with passes of 1 MiB: 1, 2, 3 and 7 passes, blocks of 64 KiB and 1 MiB,
+    matches that reach across the seams of blocks and passes."""
+    monkeypatch.setenv("ZLIB_AMD_INFLATE_PASS_MIB", "1")
+    rng = random.Random(32)
+    period = bytes(rng.randrange(256) for _ in range(30_000))
+    for data, chunk in ((za.corpus("text", 1 << 20, seed=61), 1 << 16), (za.corpus("mixed", (2 << 20) - 5, seed=62), 1 << 16),
+                        (period * 100, 1 << 16), (za.corpus("mixed", (6 << 20) + 4321, seed=63), 1 << 20),
+                        (za.corpus("text", (3 << 20) + 1, seed=64), 1 << 20)):
+        stream, offs, got = _blocks_round_trip(za, data, chunk, za.Strategy.Dynamic)
+        assert got == data, (len(data), chunk)
+    # the same call twice in a row (the halves of the buffers and the events are reused)
+    stream, offs, got = _blocks_round_trip(za, data, chunk, za.Strategy.Dynamic)
+    assert got == data
+
+
 def test_all_blocks_at_once_refuses_what_does_not_fit(za):
     import torch
     data = za.corpus("text", 200_000, seed=51)

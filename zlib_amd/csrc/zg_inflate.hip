@@ -970,31 +970,51 @@ __global__ __launch_bounds__(256) void k_resolve_all(const uint16_t *__restrict_
     }
 }
 
-// Blocks are decoded `pass_blocks` at a time: tok holds pass_blocks * inflate_tok_stride(chunk) entries, units
-// pass_blocks * chunk, ntok pass_blocks; win 32 KiB and status one entry per block of the stream (+ 2).
+// Blocks are decoded `pass_blocks` at a time: a pass takes pass_blocks * inflate_tok_stride(chunk) entries of tok,
+// pass_blocks * chunk of units, pass_blocks of ntok; win 32 KiB and status one entry per block of the stream (+ 2).
 uint64_t inflate_tok_stride(uint64_t chunk) { return (chunk + 64 + 63) & ~(uint64_t)63; }
 
+// Two passes are in flight: while the tokens of pass p are expanded and resolved on stream s2, pass p + 1 is decoded
+// on stream s (the decoder keeps the scalar units busy, the expander the vector units and the LDS).  tok, ntok and
+// units hold two passes each (the second `pass` entries behind the first); ev: four events of the caller's.
 hipError_t launch_inflate_blocks(const uint8_t *in, uint64_t in_bytes, const uint64_t *bit_off, uint32_t n_blocks,
                                  uint64_t chunk, uint64_t out_total, uint32_t pass_blocks, uint32_t *tok, uint32_t *ntok,
-                                 uint16_t *units, uint8_t *win, uint8_t *out, uint32_t *status, hipStream_t s) {
+                                 uint16_t *units, uint8_t *win, uint8_t *out, uint32_t *status, hipStream_t s,
+                                 hipStream_t s2, hipEvent_t *ev) {
     if (!n_blocks || !pass_blocks) return hipSuccess;
     // the decoder loads words: it starts from the aligned address below `in` and counts its bits from there
     const uint64_t mis = reinterpret_cast<uintptr_t>(in) & 3u;
     const uint64_t stride = inflate_tok_stride(chunk);
-    for (uint32_t b0 = 0; b0 < n_blocks; b0 += pass_blocks) {
+    hipEvent_t *const decoded = ev, *const resolved = ev + 2;
+    hipError_t e = hipEventRecord(decoded[0], s);  // what the caller has queued on s comes first on s2 as well
+    if (e == hipSuccess) e = hipStreamWaitEvent(s2, decoded[0], 0);
+    uint32_t pass = 0;
+    for (uint32_t b0 = 0; b0 < n_blocks && e == hipSuccess; b0 += pass_blocks, pass++) {
         const uint32_t b1 = n_blocks - b0 < pass_blocks ? n_blocks : b0 + pass_blocks;
         const uint64_t first = (uint64_t)b0 * chunk;
         const uint64_t n = ((uint64_t)b1 * chunk < out_total ? (uint64_t)b1 * chunk : out_total) - first;
+        const uint32_t h = pass & 1u;  // which half of the buffers
+        uint32_t *const tk = tok + (uint64_t)h * pass_blocks * stride, *const nt = ntok + (uint64_t)h * pass_blocks;
+        uint16_t *const un = units + (uint64_t)h * pass_blocks * chunk;
+        if (pass >= 2) e = hipStreamWaitEvent(s, resolved[h], 0);  // the pass before last is through with this half
+        if (e != hipSuccess) break;
         hipLaunchKernelGGL(k_decode_tokens, dim3(b1 - b0), dim3(kInfLanes), 0, s, in - mis, in_bytes + mis, bit_off, mis * 8,
-                           b0, n_blocks, chunk, out_total, tok, stride, ntok, status);
-        hipLaunchKernelGGL(k_expand_tokens, dim3(b1 - b0), dim3(kInfLanes), 0, s, tok, stride, ntok, b0, chunk, units);
-        if (n_blocks > 1)
-            hipLaunchKernelGGL(k_resolve_windows, dim3(1), dim3(1024), 0, s, units, b0, b1, n_blocks, chunk, win);
+                           b0, n_blocks, chunk, out_total, tk, stride, nt, status);
+        e = hipEventRecord(decoded[h], s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s2, decoded[h], 0);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_expand_tokens, dim3(b1 - b0), dim3(kInfLanes), 0, s2, tk, stride, nt, b0, chunk, un);
+        if (n_blocks > 1)  // (in block order: the passes follow one another on s2)
+            hipLaunchKernelGGL(k_resolve_windows, dim3(1), dim3(1024), 0, s2, un, b0, b1, n_blocks, chunk, win);
         if (n)
-            hipLaunchKernelGGL(k_resolve_all, dim3((uint32_t)((n + 2047) / 2048)), dim3(256), 0, s, units, first, n, chunk,
+            hipLaunchKernelGGL(k_resolve_all, dim3((uint32_t)((n + 2047) / 2048)), dim3(256), 0, s2, un, first, n, chunk,
                                win, out);
+        e = hipEventRecord(resolved[h], s2);
     }
-    return hipGetLastError();
+    // s goes on when everything on s2 is done
+    if (e == hipSuccess && pass >= 1) e = hipStreamWaitEvent(s, resolved[(pass - 1) & 1u], 0);
+    if (e == hipSuccess && pass >= 2) e = hipStreamWaitEvent(s, resolved[pass & 1u], 0);
+    return e == hipSuccess ? hipGetLastError() : e;
 }
 
 hipError_t launch_inflate(const uint8_t *in, const uint64_t *in_off, uint32_t n_streams, uint8_t *out,

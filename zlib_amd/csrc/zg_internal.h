@@ -208,7 +208,8 @@ hipError_t launch_inflate(const uint8_t *in, const uint64_t *in_off, uint32_t n_
 uint64_t inflate_tok_stride(uint64_t chunk);
 hipError_t launch_inflate_blocks(const uint8_t *in, uint64_t in_bytes, const uint64_t *bit_off, uint32_t n_blocks,
                                  uint64_t chunk, uint64_t out_total, uint32_t pass_blocks, uint32_t *tok, uint32_t *ntok,
-                                 uint16_t *units, uint8_t *win, uint8_t *out, uint32_t *status, hipStream_t s);
+                                 uint16_t *units, uint8_t *win, uint8_t *out, uint32_t *status, hipStream_t s,
+                                 hipStream_t s2, hipEvent_t *ev);
 hipError_t launch_trailer(uint8_t *out, const uint64_t *total_bits, const uint32_t *adler_state,
                           uint32_t adler_override, int use_override, int write_header, int write_adler,
                           uint64_t *out_bytes, hipStream_t s);
