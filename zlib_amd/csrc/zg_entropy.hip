@@ -614,7 +614,7 @@ __device__ void wave_huff_codes(const uint8_t *len, int n, uint32_t *tab, uint32
 // run-length items of one vector of code lengths (rle_lengths) with all lanes: every lane that stands on the
 // first element of a run codes that run (rle_run, first to count its items, then at the place a prefix sum over
 // the runs gives it).  n <= 320; returns the index behind the last item (uniform).
-__device__ int wave_rle_lengths(const uint8_t *cl, int n, uint8_t *rsym, uint8_t *rextra, int out, uint32_t lane) {
+__device__ __forceinline__ int wave_rle_lengths(const uint8_t *cl, int n, uint8_t *rsym, uint8_t *rextra, int out, uint32_t lane) {
     constexpr int kGroups = 5;
     uint64_t starts[kGroups];
 #pragma unroll
