@@ -553,7 +553,7 @@ def test_record_batch_large_records_and_device_entry(za, z):
     recs = [za.corpus("text", 70_000, seed=1), za.corpus("mixed", 40_000, seed=2), b"", za.corpus("text", 33_000, seed=4)]
     for r, g in zip(recs, za.compress_batch(recs)):
         _same(g, z.compress_chunked(r, z.DYNAMIC, 1 << 20, fast=True), len(r))
-    # device entry point, 5000 records of 4 KiB: spans more than one pass over the scratch buffers
+    # device entry point, 5000 records of 4 KiB
     n, stride = 5000, 4096
     data = za.corpus("records", n * stride)
     d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
@@ -596,7 +596,7 @@ def test_record_batch_into_a_dirty_buffer(za, z, strategy):
         assert off[0] == 0 and off[n] == total
         for i, r in enumerate(recs):
             _same(out[off[i]:off[i + 1]], z.compress_chunked(r, zs, 1 << 20, fast=True), (strategy, n, i, len(r)))
-    n, stride = 40_000, 4096  # 160 MB: two passes over the scratch buffers
+    n, stride = 70_000, 4096  # 287 MB: two passes over the scratch buffers (65 535 records to a pass)
     d_in = torch.empty(n * stride, dtype=torch.uint8, device="cuda")
     host = torch.empty(n * stride, dtype=torch.uint8)
     za.corpus_into("records", host.data_ptr(), n * stride, seed=9)
@@ -608,9 +608,9 @@ def test_record_batch_into_a_dirty_buffer(za, z, strategy):
     off = d_off.cpu().tolist()
     out = d_out[:total].cpu().numpy().tobytes()
     data = host.numpy().tobytes()
-    for i in list(range(0, n, 211)) + [32767, 32768, 32769, n - 1]:  # the pass seam is at record 32768
+    for i in list(range(0, n, 211)) + [65534, 65535, 65536, n - 1]:  # the pass seam is at record 65535
         assert sysz.decompress(out[off[i]:off[i + 1]]) == data[i * stride:(i + 1) * stride], i
-    for i in (0, 32767, 32768, n - 1):
+    for i in (0, 65534, 65535, n - 1):
         _same(out[off[i]:off[i + 1]], z.compress_chunked(data[i * stride:(i + 1) * stride], zs, 1 << 20, fast=True), i)
 
 

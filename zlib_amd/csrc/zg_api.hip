@@ -755,9 +755,14 @@ int compress_batch_once(zg_ctx *c, const uint8_t *d_in, size_t stride, const uin
     g.chunk_len = d_len;
     g.isolated = 1;
     const uint32_t max_tiles = max_tiles_for(stride);
-    size_t bc = ((size_t)128 << 20) / stride;
+    size_t bc = ((size_t)256 << 20) / stride;  // records per pass over the scratch buffers
+    if (const char *e = getenv("ZLIB_AMD_BATCH_PASS_MIB"))  // measurement hook
+        if (atoi(e) > 0) bc = ((size_t)atoi(e) << 20) / stride;
     if (bc < 1) bc = 1;
-    if (bc > 32768) bc = 32768;
+    // a record is a row of the kernels' grids: 65 535 at most -- which is also 32 whole fillings of the machine by
+    // the match kernel's workgroups (passes of equal size, 61 681 records for a million, were slower than sixteen of
+    // 65 535 and one of sixteen)
+    if (bc > 65535) bc = 65535;
     if (bc > n_records) bc = n_records;
     rc = ensure_chunk_meta(c, bc, max_tiles);
     if (rc) return rc;
