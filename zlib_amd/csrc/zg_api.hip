@@ -58,6 +58,7 @@ struct Scalars {
     uint32_t status;      // bit 0: output capacity exceeded, bit 1: index exchange out of order, bit 2: the parse
                           // stood on a position the walk kernel had not searched
     uint32_t pad;
+    uint64_t carry2;      // record batches: the passes' running byte offset alternates between carry and carry2
 };
 
 // Scratch of zg_adler32_device_noalloc: a fixed array in the code object, of which every GPU the library runs
@@ -88,7 +89,8 @@ struct zg_ctx {
     // shard state kept between zg_shard_begin and zg_shard_finish
     bool shard_active = false;
     uint64_t shard_total_bits = 0;
-    hipEvent_t inf_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // zg_decompress_blocks_device: two passes in flight
+    hipEvent_t inf_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // zg_decompress_blocks_device: two passes in flight;
+                                                                   // record batches: the checksums' stream
     // state of a piecewise shard run (zg_shard_open / zg_shard_next)
     struct ShardRun {
         bool open = false;
@@ -768,18 +770,37 @@ int compress_batch_once(zg_ctx *c, const uint8_t *d_in, size_t stride, const uin
     if (rc) return rc;
     HIPCHK(c->adler_part.ensure(bc * 2 * sizeof(uint32_t)));
     const MatchParams mp{kMaxWindow, 3, 258};  // get_zlib_compressor, src/compress.rs:451-456
-    for (uint32_t c0 = 0; c0 < g.n_chunks; c0 += (uint32_t)bc) {
+    // The checksums need nothing but the records: they are taken on the second stream while the first computes the
+    // streams' offsets and packs the bits (kernels of few workgroups among them).  Under the phase timers and the
+    // launch trace everything stays on one stream.
+    const bool side = !c->prof && !g_trace;
+    if (side)
+        for (int i = 0; i < 2; i++)
+            if (!c->inf_ev[i]) HIPCHK(hipEventCreateWithFlags(&c->inf_ev[i], hipEventDisableTiming));
+    hipStream_t s_adler = side ? c->copy : c->stream;
+    uint32_t pass = 0;
+    for (uint32_t c0 = 0; c0 < g.n_chunks; c0 += (uint32_t)bc, pass++) {
         const uint32_t c1 = (uint32_t)std::min<uint64_t>(g.n_chunks, (uint64_t)c0 + bc);
         rc = run_front(c, g, c0, c1, mp, strategy, kAllFinal, true);
         if (rc) return rc;
         const uint64_t bs = (uint64_t)c0 * stride;
+        if (side) {
+            // (in the first stream's order this is behind the frame kernel of the pass before, the last reader of
+            // the checksums)
+            HIPCHK(hipEventRecord(c->inf_ev[0], c->stream));
+            HIPCHK(hipStreamWaitEvent(s_adler, c->inf_ev[0], 0));
+            HIPCHK(launch_adler(d_in + bs, (uint64_t)(c1 - c0) * stride, stride, c1 - c0, d_len ? d_len + c0 : nullptr,
+                                c->adler_part.as<uint32_t>(), s_adler));
+            HIPCHK(hipEventRecord(c->inf_ev[1], s_adler));
+        }
         LAUNCH(K_TILEBITS, launch_tile_bits(c1 - c0, max_tiles, c->tokens.as<uint32_t>(), g, c0, bs,
                                             c->ntok.as<uint32_t>(), c->tab.as<uint32_t>(), c->tile_bits.as<uint32_t>(),
                                             c->stream));
         LAUNCH(K_OFFSETS, launch_tile_scan(c1 - c0, max_tiles, c->ntok.as<uint32_t>(), c->tile_bits.as<uint32_t>(),
                                            c->stream));
         LAUNCH(K_OFFSETS, launch_batch_offsets(c1 - c0, c->block_bits.as<uint64_t>(), c->bit_off.as<uint64_t>(),
-                                               &sc->carry, d_off + c0, c->stream));
+                                               (pass & 1u) ? &sc->carry2 : &sc->carry,
+                                               (pass & 1u) ? &sc->carry : &sc->carry2, d_off + c0, c->stream));
         // the words k_encode ORs into; the rest of the output needs no clearing
         LAUNCH(K_OFFSETS, launch_zero_seams(c1 - c0, max_tiles, c->ntok.as<uint32_t>(), c->hdr_bits.as<uint32_t>(),
                                             c->tile_bits.as<uint32_t>(), c->bit_off.as<uint64_t>(),
@@ -790,8 +811,11 @@ int compress_batch_once(zg_ctx *c, const uint8_t *d_in, size_t stride, const uin
                                        c->tile_bits.as<uint32_t>(), c->bit_off.as<uint64_t>(),
                                        reinterpret_cast<uint32_t *>(d_out), (uint64_t)out_cap * 8, &sc->status,
                                        c->stream));
-        LAUNCH(K_ADLER, launch_adler(d_in + bs, (uint64_t)(c1 - c0) * stride, stride, c1 - c0,
-                                     d_len ? d_len + c0 : nullptr, c->adler_part.as<uint32_t>(), c->stream));
+        if (side)
+            HIPCHK(hipStreamWaitEvent(c->stream, c->inf_ev[1], 0));
+        else
+            LAUNCH(K_ADLER, launch_adler(d_in + bs, (uint64_t)(c1 - c0) * stride, stride, c1 - c0,
+                                         d_len ? d_len + c0 : nullptr, c->adler_part.as<uint32_t>(), c->stream));
         LAUNCH(K_MISC, launch_batch_frame(c1 - c0, c->block_bits.as<uint64_t>(), d_off + c0,
                                           c->adler_part.as<uint32_t>(), d_out, c->stream));
     }
@@ -802,7 +826,7 @@ int compress_batch_once(zg_ctx *c, const uint8_t *d_in, size_t stride, const uin
     if (h.status & 2u) return kRetrySafe;  // the exchange-order check of the index kernel tripped
     if (h.status & 4u) return kRetryNoWalk;
     if (h.status & 1u) return ZG_ERR_CAPACITY;
-    *out_bytes = (size_t)h.carry;
+    *out_bytes = (size_t)((pass & 1u) ? h.carry2 : h.carry);
     return ZG_OK;
 }
 
@@ -816,6 +840,7 @@ int compress_batch_locked(zg_ctx *c, const uint8_t *d_in, size_t stride, const u
         (rc == kRetrySafe ? c->index_safe : c->walk_off) = true;
         rc = compress_batch_once(c, d_in, stride, d_len, n_records, strategy, d_out, out_cap, d_off, out_bytes);
     }
+    if (rc) (void)hipStreamSynchronize(c->copy);  // a pass's checksums may still be under way
     return (rc == kRetrySafe || rc == kRetryNoWalk) ? ZG_ERR_INTERNAL : rc;
 }
 }  // namespace

@@ -331,8 +331,11 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict
                                                         const uint32_t *__restrict__ flagw,
                                                         const uint32_t *__restrict__ match, uint64_t base,
                                                         const uint32_t *__restrict__ tile_off,
+                                                        uint32_t *__restrict__ ntok_one,
                                                         uint32_t *__restrict__ tokens, uint64_t tok_base,
                                                         uint32_t *__restrict__ freq, uint32_t *__restrict__ status) {
+    // ntok_one != nullptr: chunks of one tile (tpc == 1).  The tile's units begin the chunk's and their number is
+    // the chunk's, written here: no counting pass ran and tile_off is not read.
     __shared__ uint32_t s_hist[kTabStride];
     __shared__ uint32_t s_wave[kEmitThreads / 64];
     __shared__ uint32_t s_tok[kEmitTile];
@@ -340,7 +343,10 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict
     const uint64_t cs = first + (uint64_t)(c0 + ci) * chunk_bytes;
     const uint64_t ce = chunk_end(cs, chunk_bytes, end, clen, c0 + ci);
     const uint64_t t0 = cs + (uint64_t)tile * kEmitTile;
-    if (t0 >= ce) return;
+    if (t0 >= ce) {
+        if (ntok_one && tid == 0) ntok_one[ci] = 0;
+        return;
+    }
     const uint32_t tn = (uint32_t)((ce - t0 < kEmitTile) ? ce - t0 : kEmitTile);
     for (uint32_t i = tid; i < kTabStride; i += kEmitThreads) s_hist[i] = 0;
     constexpr uint32_t kPer = kEmitTile / kEmitThreads;  // consecutive positions per thread
@@ -415,7 +421,8 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(const uint8_t *__restrict
         s_tok[o++] = tok;
     }
     __syncthreads();
-    uint32_t *tok_out = tokens + (cs - tok_base) + tile_off[(uint64_t)ci * tpc + tile];
+    uint32_t *tok_out = tokens + (cs - tok_base) + (ntok_one ? 0u : tile_off[(uint64_t)ci * tpc + tile]);
+    if (ntok_one && tid == 0) ntok_one[ci] = total;
     for (uint32_t i = tid; i < total; i += kEmitThreads) tok_out[i] = s_tok[i];
     for (uint32_t i = tid; i < kTabStride; i += kEmitThreads)
         if (s_hist[i]) atomicAdd(&freq[(uint64_t)ci * kTabStride + i], s_hist[i]);
@@ -440,13 +447,15 @@ hipError_t launch_parse(const ChunkGrid &g, uint32_t c0, uint32_t c1, const uint
                        match, base, flag, sub_exit, sub_exit2, merged);
     hipLaunchKernelGGL(k_parse_check, dim3(nc), dim3(64), 0, s, g.first, g.end, g.chunk_bytes, g.chunk_len, c0, spc, match,
                        base, flag, sub_exit2, merged);
-    hipLaunchKernelGGL(k_emit_count, dim3(tpc, nc), dim3(kEmitThreads), 0, s, spc, tpc, flag, tile_cnt);
-    if (tpc <= kScanFew)
-        hipLaunchKernelGGL(k_emit_scan_few, dim3((nc + 255) / 256), dim3(256), 0, s, nc, tpc, tile_cnt, ntok);
-    else
-        hipLaunchKernelGGL(k_emit_scan, dim3(nc), dim3(256), 0, s, tpc, tile_cnt, ntok);
+    if (tpc > 1) {
+        hipLaunchKernelGGL(k_emit_count, dim3(tpc, nc), dim3(kEmitThreads), 0, s, spc, tpc, flag, tile_cnt);
+        if (tpc <= kScanFew)
+            hipLaunchKernelGGL(k_emit_scan_few, dim3((nc + 255) / 256), dim3(256), 0, s, nc, tpc, tile_cnt, ntok);
+        else
+            hipLaunchKernelGGL(k_emit_scan, dim3(nc), dim3(256), 0, s, tpc, tile_cnt, ntok);
+    }
     hipLaunchKernelGGL(k_emit, dim3(tpc, nc), dim3(kEmitThreads), 0, s, g.data, g.first, g.end, g.chunk_bytes, g.chunk_len,
-                       c0, spc, tpc, flag, match, base, tile_cnt, tokens, tok_base, freq, status);
+                       c0, spc, tpc, flag, match, base, tile_cnt, tpc > 1 ? nullptr : ntok, tokens, tok_base, freq, status);
     return hipGetLastError();
 }
 
@@ -846,12 +855,21 @@ __global__ __launch_bounds__(kEncThreads) void k_tile_bits(uint32_t max_tiles, c
     __shared__ uint32_t s_ll[kHuffMaxSyms];
     __shared__ uint32_t s_d[32];
     __shared__ uint32_t s_red[kEncThreads / 64];
-    const uint32_t ci = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t ci = blockIdx.y, tid = threadIdx.x;
     const uint32_t nunits = ntok[ci] + 1u;  // + end of block
-    if ((uint64_t)tile * kEncTile >= nunits) return;
+    const uint32_t nt = (uint32_t)(((uint64_t)nunits + kEncTile - 1) / kEncTile);
+    // The sums are only ever added up to where a tile's bits begin: nobody asks for the last tile's (the block's
+    // length comes with its code tables).  For a block of one tile -- nearly every 4 KiB record -- there is nothing
+    // to do.
+    if (blockIdx.x == 0 && tid == 0) tile_bits[(uint64_t)ci * max_tiles + nt - 1] = 0;
+    if (blockIdx.x + 1 >= nt) return;
     for (uint32_t i = tid; i < kHuffMaxSyms; i += kEncThreads) s_ll[i] = tab[(uint64_t)ci * kTabStride + i];
     if (tid < 32) s_d[tid] = tab[(uint64_t)ci * kTabStride + kDOff + tid];
     __syncthreads();
+    // a workgroup takes the tiles blockIdx.x, blockIdx.x + gridDim.x, ...: one each when the grid has a column per
+    // tile, all of a chunk's when it has one column (chunks of few tiles: a column per possible tile would be
+    // workgroups that find nothing to do)
+    for (uint32_t tile = blockIdx.x; tile + 1 < nt; tile += gridDim.x) {
     const uint32_t *tok = tokens + (first + (uint64_t)(c0 + ci) * chunk_bytes - tok_base);
     // all of a thread's units are loaded before the first is looked at (a load inside the loop was waited for on
     // every turn); indices past the block's end are clamped and their units dropped
@@ -876,6 +894,8 @@ __global__ __launch_bounds__(kEncThreads) void k_tile_bits(uint32_t max_tiles, c
         uint32_t t = 0;
         for (uint32_t i = 0; i < kEncThreads / 64; i++) t += s_red[i];
         tile_bits[(uint64_t)ci * max_tiles + tile] = t;
+    }
+    __syncthreads();  // s_red is written again on the next turn
     }
 }
 
@@ -953,50 +973,62 @@ __global__ __launch_bounds__(256) void k_block_offsets(uint32_t n_chunks, const 
 // bytes of Adler-32 (reference src/compress.rs:51-86).  carry[0] is the byte offset of the batch's first
 // stream on entry and of the next batch's on exit.
 __global__ __launch_bounds__(1024) void k_batch_offsets(uint32_t n_chunks, const uint64_t *__restrict__ block_bits,
-                                                         uint64_t *__restrict__ bit_off, uint64_t *carry,
+                                                         uint64_t *__restrict__ bit_off,
+                                                         const uint64_t *__restrict__ carry_in,
+                                                         uint64_t *__restrict__ carry_out,
                                                          uint64_t *__restrict__ out_offsets) {
-    // 8192 streams at a time, eight neighbours per thread: a scan inside every wave, one over the 16 wave totals,
-    // the running total carried on
+    // A workgroup per 8192 streams, eight neighbours per thread.  It first adds up the lengths of all streams
+    // before its own (eight workgroups at most: the last reads 56 values per thread, all of them in the L2), then
+    // scans its own: inside every wave, then over the 16 wave totals.  The total goes to another word than the one
+    // the start is read from: a workgroup may begin after the last one has finished.
     constexpr uint32_t kPer = 8;
     __shared__ uint64_t s_wave[16];
+    __shared__ uint64_t s_before[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    uint64_t run = carry[0];
-    for (uint32_t i0 = 0; i0 < n_chunks; i0 += 1024 * kPer) {
-        const uint32_t i = i0 + tid * kPer;
-        uint64_t len[kPer], mine = 0;
+    const uint32_t i0 = blockIdx.x * 1024u * kPer;
+    uint64_t pre = 0;
+    for (uint32_t j0 = 0; j0 < i0; j0 += 1024 * kPer) {
+        uint64_t v[kPer];
 #pragma unroll
-        for (uint32_t k = 0; k < kPer; k++) {
-            len[k] = i + k < n_chunks ? 6 + ((block_bits[i + k] + 7) >> 3) : 0;
-            mine += len[k];
-        }
-        uint64_t incl = mine;
-        for (uint32_t off = 1; off < 64; off <<= 1) {
-            const uint64_t up = __shfl_up(incl, off);
-            if (lane >= off) incl += up;
-        }
-        if (lane == 63) s_wave[wv] = incl;
-        __syncthreads();
-        uint64_t before = 0, total = 0;
-        for (uint32_t w = 0; w < 16; w++) {
-            const uint64_t t = s_wave[w];
-            before += w < wv ? t : 0;
-            total += t;
-        }
-        uint64_t at = run + before + incl - mine;
+        for (uint32_t k = 0; k < kPer; k++) v[k] = block_bits[j0 + k * 1024u + tid];  // (all below i0 <= n_chunks)
 #pragma unroll
-        for (uint32_t k = 0; k < kPer; k++) {
-            if (i + k < n_chunks) {
-                out_offsets[i + k] = at;
-                bit_off[i + k] = (at + 2) * 8;
-            }
-            at += len[k];
-        }
-        run += total;
-        __syncthreads();
+        for (uint32_t k = 0; k < kPer; k++) pre += 6 + ((v[k] + 7) >> 3);
     }
-    if (tid == 0) {
-        carry[0] = run;
-        out_offsets[n_chunks] = run;  // end of the last stream (the next batch rewrites it)
+    for (int off = 32; off > 0; off >>= 1) pre += __shfl_down(pre, off);
+    if (lane == 0) s_before[wv] = pre;
+    const uint32_t i = i0 + tid * kPer;
+    uint64_t len[kPer], mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) {
+        len[k] = i + k < n_chunks ? 6 + ((block_bits[i + k] + 7) >> 3) : 0;
+        mine += len[k];
+    }
+    uint64_t incl = mine;
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        const uint64_t up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    uint64_t before = carry_in[0], total = 0;
+    for (uint32_t w = 0; w < 16; w++) {
+        const uint64_t t = s_wave[w];
+        before += s_before[w] + (w < wv ? t : 0);
+        total += t + s_before[w];
+    }
+    uint64_t at = before + incl - mine;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) {
+        if (i + k < n_chunks) {
+            out_offsets[i + k] = at;
+            bit_off[i + k] = (at + 2) * 8;
+        }
+        at += len[k];
+    }
+    if (tid == 0 && blockIdx.x + 1 == gridDim.x) {
+        const uint64_t end = carry_in[0] + total;
+        carry_out[0] = end;
+        out_offsets[n_chunks] = end;  // end of the last stream (the next batch rewrites it)
     }
 }
 __global__ __launch_bounds__(256) void k_batch_frame(uint32_t n_chunks, const uint64_t *__restrict__ block_bits,
@@ -1015,10 +1047,12 @@ __global__ __launch_bounds__(256) void k_batch_frame(uint32_t n_chunks, const ui
     t[2] = (uint8_t)(a >> 8);
     t[3] = (uint8_t)a;
 }
-hipError_t launch_batch_offsets(uint32_t n_chunks, const uint64_t *block_bits, uint64_t *bit_off, uint64_t *carry,
-                                uint64_t *out_offsets, hipStream_t s) {
+hipError_t launch_batch_offsets(uint32_t n_chunks, const uint64_t *block_bits, uint64_t *bit_off,
+                                const uint64_t *carry_in, uint64_t *carry_out, uint64_t *out_offsets, hipStream_t s) {
     if (!n_chunks) return hipSuccess;
-    hipLaunchKernelGGL(k_batch_offsets, dim3(1), dim3(1024), 0, s, n_chunks, block_bits, bit_off, carry, out_offsets);
+    if (carry_in == carry_out) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_batch_offsets, dim3((n_chunks + 8191) / 8192), dim3(1024), 0, s, n_chunks, block_bits, bit_off,
+                       carry_in, carry_out, out_offsets);
     return hipGetLastError();
 }
 hipError_t launch_batch_frame(uint32_t n_chunks, const uint64_t *block_bits, const uint64_t *out_offsets,
@@ -1033,7 +1067,9 @@ hipError_t launch_tile_bits(uint32_t n_chunks, uint32_t max_tiles, const uint32_
                             uint32_t c0, uint64_t tok_base, const uint32_t *ntok, const uint32_t *tab,
                             uint32_t *tile_bits, hipStream_t s) {
     if (!n_chunks) return hipSuccess;
-    hipLaunchKernelGGL(k_tile_bits, dim3(max_tiles, n_chunks), dim3(kEncThreads), 0, s, max_tiles, tokens, g.first,
+    // (the last possible tile is a last tile wherever it exists)
+    const uint32_t cols = max_tiles <= kScanFew ? 1u : max_tiles - 1u;
+    hipLaunchKernelGGL(k_tile_bits, dim3(cols, n_chunks), dim3(kEncThreads), 0, s, max_tiles, tokens, g.first,
                        g.chunk_bytes, c0, tok_base, ntok, tab, tile_bits);
     return hipGetLastError();
 }
@@ -1222,12 +1258,47 @@ __global__ __launch_bounds__(256) void k_zero_seams(uint32_t max_tiles, const ui
     }
 }
 
+// the same for chunks of up to 64 tiles (records): a wave per chunk instead of a workgroup of mostly idle threads
+__global__ __launch_bounds__(256) void k_zero_seams_few(uint32_t n_chunks, uint32_t max_tiles,
+                                                         const uint32_t *__restrict__ ntok,
+                                                         const uint32_t *__restrict__ hdr_bits,
+                                                         const uint32_t *__restrict__ tile_off,
+                                                         const uint64_t *__restrict__ bit_off,
+                                                         const uint64_t *__restrict__ block_bits, uint32_t *out,
+                                                         uint64_t out_cap_bits, uint32_t separate) {
+    const uint32_t ci = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (ci >= n_chunks) return;
+    const uint32_t nt = (ntok[ci] + 1u + kEncTile - 1) / kEncTile;
+    const uint64_t blk_bit = bit_off[ci], last_word = out_cap_bits >> 5;
+    const uint64_t keep = (bit_off[0] & 31u) ? bit_off[0] >> 5 : ~0ull;
+    const uint32_t hb = hdr_bits[ci];
+    if (separate && lane == 0 && (blk_bit & 31u)) {
+        uint8_t *ob = reinterpret_cast<uint8_t *>(out);
+        for (uint64_t b = blk_bit >> 3; b < ((blk_bit >> 5) + 1) * 4 && b * 8 < out_cap_bits; b++) ob[b] = 0;
+    }
+    const uint64_t w_hi = (blk_bit + hb) >> 5;
+    for (uint64_t w = ((blk_bit + 31) >> 5) + lane; w <= w_hi && w <= last_word; w += 64)
+        if (w != keep) out[w] = 0;
+    if (lane < nt) {
+        const uint64_t start_bit = blk_bit + hb + tile_off[(uint64_t)ci * max_tiles + lane];
+        const uint64_t end_bit = blk_bit + (lane + 1 < nt ? (uint64_t)hb + tile_off[(uint64_t)ci * max_tiles + lane + 1]
+                                                         : block_bits[ci]);
+        const uint64_t w = end_bit >> 5;
+        if (w <= last_word && w != keep) out[w] = 0;
+        if ((end_bit & 31u) == 0 && w > (start_bit >> 5) + 1 && w - 1 <= last_word && w - 1 != keep) out[w - 1] = 0;
+    }
+}
+
 hipError_t launch_zero_seams(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *ntok, const uint32_t *hdr_bits,
                              const uint32_t *tile_off, const uint64_t *bit_off, const uint64_t *block_bits,
                              uint32_t *out, uint64_t out_cap_bits, bool separate, hipStream_t s) {
     if (!n_chunks) return hipSuccess;
-    hipLaunchKernelGGL(k_zero_seams, dim3((max_tiles + 255) / 256, n_chunks), dim3(256), 0, s, max_tiles, ntok, hdr_bits,
-                       tile_off, bit_off, block_bits, out, out_cap_bits, separate ? 1u : 0u);
+    if (max_tiles <= 64)
+        hipLaunchKernelGGL(k_zero_seams_few, dim3((n_chunks + 3) / 4), dim3(256), 0, s, n_chunks, max_tiles, ntok, hdr_bits,
+                           tile_off, bit_off, block_bits, out, out_cap_bits, separate ? 1u : 0u);
+    else
+        hipLaunchKernelGGL(k_zero_seams, dim3((max_tiles + 255) / 256, n_chunks), dim3(256), 0, s, max_tiles, ntok,
+                           hdr_bits, tile_off, bit_off, block_bits, out, out_cap_bits, separate ? 1u : 0u);
     return hipGetLastError();
 }
 

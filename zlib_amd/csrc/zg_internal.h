@@ -169,10 +169,11 @@ hipError_t launch_encode(uint32_t n_chunks, uint32_t max_tiles, const uint32_t *
 // per segment (a, b) of a stream starting at (1, 0); seg_len, when set, holds each segment's byte count
 hipError_t launch_adler(const uint8_t *data, uint64_t n, uint64_t seg_bytes, uint32_t n_seg, const uint32_t *seg_len,
                         uint32_t *partial, hipStream_t s);
-// record batches: byte offset of every record's stream (running total in carry[0]) and its block's bit offset;
-// then the two header bytes and the Adler-32 around every block
-hipError_t launch_batch_offsets(uint32_t n_chunks, const uint64_t *block_bits, uint64_t *bit_off, uint64_t *carry,
-                                uint64_t *out_offsets, hipStream_t s);
+// record batches: byte offset of every record's stream (the batch's first in carry_in[0], the next batch's first
+// to carry_out[0], which must be another word) and its block's bit offset; then the two header bytes and the
+// Adler-32 around every block
+hipError_t launch_batch_offsets(uint32_t n_chunks, const uint64_t *block_bits, uint64_t *bit_off,
+                                const uint64_t *carry_in, uint64_t *carry_out, uint64_t *out_offsets, hipStream_t s);
 hipError_t launch_batch_frame(uint32_t n_chunks, const uint64_t *block_bits, const uint64_t *out_offsets,
                               const uint32_t *adler_part, uint8_t *out, hipStream_t s);
 hipError_t launch_adler_fold(const uint32_t *partial, uint64_t n, uint64_t seg_bytes, uint32_t n_seg,
