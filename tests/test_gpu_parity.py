@@ -571,6 +571,37 @@ def test_record_batch_large_records_and_device_entry(za, z):
     assert sysz.decompress(out[off[n - 1]:off[n]]) == data[(n - 1) * stride:]
 
 
+def test_record_batch_in_many_passes_and_under_the_phase_timers(za, z, monkeypatch):
+    """Passes of 1 MiB (256 records of 4 KiB, 777 of them in 4 passes; 1300 of 1 KiB in 2): the streams' running byte
+    offset changes words from pass to pass and the checksums of a pass are taken on a second stream beside its bit
+    packing; with the phase timers on, everything stays on one stream.  The result is the same either way, and
+    every stream is the oracle's."""
+    import torch
+    monkeypatch.setenv("ZLIB_AMD_BATCH_PASS_MIB", "1")
+    ctx = za.default_context()
+    for n, stride in ((777, 4096), (1300, 1024), (256, 4096), (257, 4096)):
+        data = za.corpus("records", n * stride, seed=n)
+        d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        cap = za.compress_batch_bound(stride, n)
+        outs = []
+        for timers in (False, True, False):
+            ctx.profile(timers)
+            try:
+                d_out = torch.full((cap,), 0x55, dtype=torch.uint8, device="cuda")
+                d_off = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+                total = za.compress_batch_device(d_in.data_ptr(), stride, 0, n, d_out.data_ptr(), cap, d_off.data_ptr(), ctx=ctx)
+            finally:
+                ctx.profile(False)
+            off = d_off.cpu().tolist()
+            assert off[0] == 0 and off[n] == total and all(a < b for a, b in zip(off, off[1:]))
+            outs.append((off, d_out[:total].cpu().numpy().tobytes()))
+        assert outs[0] == outs[1] == outs[2]
+        off, out = outs[0]
+        for i in list(range(0, n, 41)) + [255, n - 1]:
+            rec = data[i * stride:(i + 1) * stride]
+            _same(out[off[i]:off[i + 1]], z.compress_chunked(rec, z.DYNAMIC, 1 << 20, fast=True), (n, stride, i))
+
+
 @pytest.mark.parametrize("strategy", ["Dynamic", "Fixed"])
 def test_record_batch_into_a_dirty_buffer(za, z, strategy):
     """The record path clears only the words its bit packer ORs into, not the output: every byte of every stream must
