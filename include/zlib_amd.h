@@ -9,8 +9,12 @@
  *
  * Conventions: 0 = success, negative = error (zg_strerror); the library
  * allocates host outputs with malloc and the caller releases them with
- * zg_free; nothing unwinds or aborts across the boundary.  A zg_ctx owns one
- * HIP stream and its scratch buffers on one device; calls on the same ctx are
+ * zg_free; nothing unwinds or aborts across the boundary.  A zg_ctx owns its
+ * HIP streams (the one its kernels run on and a second for uploads, the
+ * second half of overlapped passes and the checksums of record batches) and
+ * its scratch buffers on one device; device inputs must be complete when a
+ * call is made (these streams are not ordered after the caller's).
+ * Calls on the same ctx are
  * serialised by an internal mutex, different ctx objects are independent.
  * Passing ctx == NULL uses a lazily created process-wide context on the
  * current HIP device.
