@@ -1,5 +1,5 @@
 """The multi-rank assembly logic (zlib_amd/sharding.py) over gloo on the CPU,
-world size 2 and 3.  The per-rank compute is replaced by a stand-in engine that
+world size 2, 3, 4 and 8.  The per-rank compute is replaced by a stand-in engine that
 produces, from the oracle, exactly what zg_shard_begin / zg_shard_finish return
 on a GPU; what is tested is the exchange: bit totals and Adler parts gathered,
 bit phases, the shared boundary byte, the payload sends."""
@@ -140,6 +140,8 @@ def _piece_worker(rank, world, port, total, chunk, pass_chunks, q, piece=None, f
     (3, 20_000, 8192, 1, None),     # 3 chunks over 3 ranks, the last one short
     (3, 10_000, 8192, 2, None),     # 2 chunks over 3 ranks: the first rank has no input and adds nothing
     (2, 0, 8192, 2, None),          # no input at all: the last rank writes the one empty block
+    (4, 130_000, 8192, 2, None),    # 16 chunks over 4 ranks, two passes each
+    (8, 200_000, 8192, 1, 3000),    # as many ranks as a node has GPUs: 25 chunks, 3 or 4 a rank, pieces in several sends
 ])
 def test_overlapped_assembly_equals_single_stream(world, total, chunk, pass_chunks, piece):
     """The exchange that runs beside the kernels: per pass one all_gather of piece sizes and one send of the bytes
