@@ -574,8 +574,8 @@ def test_record_batch_large_records_and_device_entry(za, z):
 def test_record_batch_in_many_passes_and_under_the_phase_timers(za, z, monkeypatch):
     """Passes of 1 MiB (256 records of 4 KiB, 777 of them in 4 passes; 1300 of 1 KiB in 2): the streams' running byte
     offset changes words from pass to pass and the checksums of a pass are taken on a second stream beside its bit
-    packing; with the phase timers on, everything stays on one stream.  The result is the same either way, and
-    every stream is the oracle's."""
+    packing, with or without the phase timers' events around every launch.  The result is the same either way,
+    and every stream is the oracle's."""
     import torch
     monkeypatch.setenv("ZLIB_AMD_BATCH_PASS_MIB", "1")
     ctx = za.default_context()

@@ -146,14 +146,15 @@ int fail_hip(zg_ctx *c, hipError_t e, const char *what) {
 struct ProfScope {
     zg_ctx *c;
     int id;
+    hipStream_t s;  // the stream the bracketed launches go to
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(zg_ctx *c_, int id_) : c(c_), id(id_) {
+    ProfScope(zg_ctx *c_, int id_, hipStream_t s_ = nullptr) : c(c_), id(id_), s(s_ ? s_ : c_->stream) {
         if (c->prof && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
-            (void)hipEventRecord(a, c->stream);
+            (void)hipEventRecord(a, s);
     }
     ~ProfScope() {
         if (a && b) {
-            (void)hipEventRecord(b, c->stream);
+            (void)hipEventRecord(b, s);
             c->events.push_back({id, a, b});
         }
     }
@@ -771,9 +772,9 @@ int compress_batch_once(zg_ctx *c, const uint8_t *d_in, size_t stride, const uin
     HIPCHK(c->adler_part.ensure(bc * 2 * sizeof(uint32_t)));
     const MatchParams mp{kMaxWindow, 3, 258};  // get_zlib_compressor, src/compress.rs:451-456
     // The checksums need nothing but the records: they are taken on the second stream while the first computes the
-    // streams' offsets and packs the bits (kernels of few workgroups among them).  Under the phase timers and the
-    // launch trace everything stays on one stream.
-    const bool side = !c->prof && !g_trace;
+    // streams' offsets and packs the bits (kernels of few workgroups among them).  Under the launch trace everything
+    // stays on one stream.
+    const bool side = !g_trace;
     if (side)
         for (int i = 0; i < 2; i++)
             if (!c->inf_ev[i]) HIPCHK(hipEventCreateWithFlags(&c->inf_ev[i], hipEventDisableTiming));
@@ -789,8 +790,11 @@ int compress_batch_once(zg_ctx *c, const uint8_t *d_in, size_t stride, const uin
             // the checksums)
             HIPCHK(hipEventRecord(c->inf_ev[0], c->stream));
             HIPCHK(hipStreamWaitEvent(s_adler, c->inf_ev[0], 0));
-            HIPCHK(launch_adler(d_in + bs, (uint64_t)(c1 - c0) * stride, stride, c1 - c0, d_len ? d_len + c0 : nullptr,
-                                c->adler_part.as<uint32_t>(), s_adler));
+            {
+                ProfScope ps_(c, K_ADLER, s_adler);
+                HIPCHK(launch_adler(d_in + bs, (uint64_t)(c1 - c0) * stride, stride, c1 - c0,
+                                    d_len ? d_len + c0 : nullptr, c->adler_part.as<uint32_t>(), s_adler));
+            }
             HIPCHK(hipEventRecord(c->inf_ev[1], s_adler));
         }
         LAUNCH(K_TILEBITS, launch_tile_bits(c1 - c0, max_tiles, c->tokens.as<uint32_t>(), g, c0, bs,
