@@ -269,7 +269,19 @@ def run_workload(name, steps, warmup, env, verify=True, shard_path=False, exchan
 
     for _ in range(warmup):
         out_n = step()
+    # One untimed step with HIP events around every kernel launch: the breakdown per kernel, and which kernel
+    # dominates.  In the timed steps only that kernel's launches carry events (they give the roofline's duration);
+    # events around all of them cost a step about one per cent.  ZG_BENCH_TIMERS=all / 0: every kernel / none in
+    # the timed steps (measurement hook).
+    timers = os.environ.get("ZG_BENCH_TIMERS", "dominant")
     ctx.profile(True)
+    ctx.profile_reset()
+    sync()
+    out_n = step()
+    sync()
+    prof = ctx.profile_get()
+    dominant = max(((k, v) for k, v in prof.items() if k != "misc"), key=lambda kv: kv[1][0])[0]
+    ctx.profile(timers != "0", only=None if timers == "all" else dominant)
     ctx.profile_reset()
     sync()
     t0 = time.perf_counter()
@@ -281,7 +293,7 @@ def run_workload(name, steps, warmup, env, verify=True, shard_path=False, exchan
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    prof = ctx.profile_get()
+    prof_timed = ctx.profile_get()
     ctx.profile(False)
 
     verified, inflate_ms = None, None
@@ -319,6 +331,7 @@ def run_workload(name, steps, warmup, env, verify=True, shard_path=False, exchan
                 raise SystemExit("round trip through system zlib FAILED")
     res = {"name": name, "kind": kind, "strategy": strat_name, "chunk": chunk, "seed": seed, "total": total, "n": n,
            "strong": strong, "batch": batch, "dt": dt, "steps": steps, "out_n": out_n, "prof": prof,
+           "dominant": dominant, "dominant_timed": prof_timed[dominant],
            "verified": verified, "inflate_ms": inflate_ms}
     del d_in, d_out, final
     torch.cuda.empty_cache()
@@ -326,13 +339,17 @@ def run_workload(name, steps, warmup, env, verify=True, shard_path=False, exchan
 
 
 def kernel_roofline(res, workload_for_traffic, world):
-    """The dominant kernel of the step by accumulated event time, priced on algorithmic bytes."""
-    prof, steps = res["prof"], res["steps"]
-    kname, (kms, kn) = max(((k, v) for k, v in prof.items() if k != "misc"), key=lambda kv: kv[1][0])
+    """The dominant kernel of a step by event time, priced on algorithmic bytes; its duration is the mean over its
+    launches in the timed steps."""
+    steps = res["steps"]
+    kname, (kms, kn) = res["dominant"], res["dominant_timed"]
     k_avg_ms = kms / max(1, kn)
     launches_per_step = kn / steps
     ratio = res["out_n"] / res["total"]
     bytes_per_launch = res["n"] * (1.0 + ratio) / max(1.0, launches_per_step)  # this rank's share
+    if k_avg_ms <= 0:  # ZG_BENCH_TIMERS=0: nothing was timed per kernel
+        return {"bound": "hbm", "kernel": kname, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                "traffic": None, "kernel_avg_ms": None, "launches_per_step": None}
     achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9
     traffic, stale = measured_traffic(workload_for_traffic, kname, k_avg_ms) if world == 1 else (None, None)
     return {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -416,7 +433,9 @@ def main():
                        "inflate_on_device_ms": res["inflate_ms"],
                        "parallelism": par},
             "roofline": roof,
-            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in res["prof"].items() if v[1]},
+            "kernels_ms_per_step": {k: v[0] for k, v in res["prof"].items() if v[1]},
+            "kernels_ms_per_step_note": "HIP events around every launch in one untimed step before the timed ones; in "
+                                        "the timed steps only the dominant kernel's launches carry events (roofline)",
         }
     headline = args.workload == "mixed8g"
     if world == 1 and headline and not args.no_others:

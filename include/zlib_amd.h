@@ -291,8 +291,10 @@ int zg_huffman_from_tokens(zg_ctx *ctx, const uint32_t *tokens, size_t n, uint8_
 
 /* ---- measurement ----
  * With profiling on, every kernel launch is bracketed by HIP events on the
- * ctx stream; zg_profile_get returns accumulated milliseconds and launch
- * counts per kernel since the last zg_profile_reset. */
+ * stream it goes to; zg_profile_get returns accumulated milliseconds and launch
+ * counts per kernel since the last zg_profile_reset.  on = 0: off; 1: every
+ * kernel; 2 + i: only the kernel that zg_profile_get reports at index i (the
+ * events of the others cost a long call about one per cent). */
 int zg_profile_enable(zg_ctx *ctx, int on);
 int zg_profile_reset(zg_ctx *ctx);
 int zg_profile_count(zg_ctx *ctx);

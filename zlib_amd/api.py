@@ -63,8 +63,12 @@ class Context:
             pass
 
     # -- measurement -------------------------------------------------------
-    def profile(self, on: bool = True):
-        _check(_lib.lib().zg_profile_enable(self._h, int(on)), self)
+    def profile(self, on: bool = True, only: Optional[str] = None):
+        """Phase timers on or off; `only`: the name of the one kernel to time (as profile_get reports it)."""
+        mode = int(bool(on))
+        if on and only is not None:
+            mode = 2 + list(self.profile_get()).index(only)
+        _check(_lib.lib().zg_profile_enable(self._h, mode), self)
 
     def profile_reset(self):
         _check(_lib.lib().zg_profile_reset(self._h), self)

@@ -119,6 +119,7 @@ struct zg_ctx {
     std::vector<uint64_t> block_offs;
     // profiling
     bool prof = false;
+    int prof_only = -1;  // >= 0: only launches of this kernel id are timed
     struct Ev {
         int id;
         hipEvent_t a, b;
@@ -149,7 +150,8 @@ struct ProfScope {
     hipStream_t s;  // the stream the bracketed launches go to
     hipEvent_t a = nullptr, b = nullptr;
     ProfScope(zg_ctx *c_, int id_, hipStream_t s_ = nullptr) : c(c_), id(id_), s(s_ ? s_ : c_->stream) {
-        if (c->prof && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+        if (c->prof && (c->prof_only < 0 || c->prof_only == id_) && hipEventCreate(&a) == hipSuccess &&
+            hipEventCreate(&b) == hipSuccess)
             (void)hipEventRecord(a, s);
     }
     ~ProfScope() {
@@ -2223,7 +2225,9 @@ int zg_profile_enable(zg_ctx *ctx, int on) {
     zg_ctx *c = resolve(ctx, &rc);
     if (!c) return rc ? rc : ZG_ERR_NO_DEVICE;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (on < 0 || on >= 2 + K_COUNT) return ZG_ERR_ARG;
     c->prof = on != 0;
+    c->prof_only = on >= 2 ? on - 2 : -1;
     return ZG_OK;
 }
 int zg_profile_reset(zg_ctx *ctx) {
