@@ -1,3 +1,4 @@
+# bench.py with events around every launch, around the dominant kernel only, and with none in the timed steps
 set -o pipefail
 for w in mixed8g records4g text64m; do
 for t in all dominant 0; do
